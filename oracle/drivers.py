@@ -1,0 +1,223 @@
+"""Drivers / scripts of the reference restated (TEST INFRASTRUCTURE, see oracle/__init__.py)."""
+import numpy as np
+import scipy.sparse as sp
+
+from . import operators as ops
+from . import prox as px
+from .chambolle_pock import chambolle_pock
+
+
+def normalize(x):
+    x = np.asarray(x, dtype=np.float64)
+    return (x - x.min()) / (x.max() - x.min())
+
+
+def normest_start(n):
+    """Deterministic replacement for randn in NNE/matrix_norm.m:22 (the reference is
+    non-deterministic there).  x_i = ((i * 2654435761) mod 2^32) / 2^31 - 1, i = 0..n-1,
+    exactly representable in fp64, so the engine reproduces it bit for bit."""
+    i = np.arange(n, dtype=np.uint64)
+    hsh = (i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    return hsh.astype(np.float64) / 2147483648.0 - 1.0
+
+
+# --------------------------------------------------------------------------
+# PDO/test_TV_L1_registration.m:56-122 / PDO/test_TV_L2_registration.m:56-122
+def tv_registration(R, T, lam, tau, maxIter, numSteps, data_term="SAD", h=(1.0, 1.0), theta=1.0,
+                    keep_histories=False):
+    R = normalize(R)
+    T = normalize(T)
+    m, n = R.shape
+    K = ops.pairwise_gradient(m, n, h, 2)
+    L_squared = 4 * (1 / h[0] ** 2 + 1 / h[1] ** 2)                              # (:75)
+    u0 = np.zeros(m * n * 2)
+    v0 = np.zeros(m * n * 4)
+    sigma = (1 - 1e-4) / (L_squared * tau)                                       # (:81)
+    Gfun = px.SAD_registration if data_term == "SAD" else px.SSD_registration
+    F = lambda v, c, nargout: px.TV_registration(v, sigma, c, nargout)
+    hist = []
+    for _ in range(numSteps):                                                    # (:94)
+        G = (lambda u0_: (lambda u, c, nargout: Gfun(u, u0_, T, R, h, lam, tau, c, nargout)))(u0.copy())
+        u_star, v_star, ph, dh = chambolle_pock(F, G, K, u0, v0, theta, tau, sigma, maxIter)   # tol default
+        u0, v0 = u_star, v_star                                                  # (:119)
+        if keep_histories:
+            hist.append((ph, dh))
+    return u0, v0, hist, dict(sigma=sigma, R=R, T=T)
+
+
+# PDO/test_TV_L1_denoising.m:29-63
+def tv_l1_denoising(img_noisy, lam=1.5, tau=0.02, maxIter=1000, tol=1e-5, h=(1.0, 1.0), theta=1.0):
+    img_noisy = np.asarray(img_noisy, dtype=np.float64)
+    m, n = img_noisy.shape
+    K = ops.pairwise_gradient(m, n, h, 1)
+    L_squared = 4 * (1 / h[0] ** 2 + 1 / h[1] ** 2)
+    sigma = (1 - 1e-4) / (L_squared * tau)
+    g = img_noisy.reshape(-1, order="F")
+    G = lambda u, c, nargout: px.SAD_denoise(u, g, lam, tau, c, nargout)
+    F = lambda v, c, nargout: px.TV_denoise(v, sigma, c, nargout)
+    return chambolle_pock(F, G, K, np.zeros(m * n), np.zeros(2 * m * n), theta, tau, sigma, maxIter, tol) + (sigma,)
+
+
+# --------------------------------------------------------------------------
+# NNE/mf_nn_tv_registration_no_ref_ml.m / NNE/mf_nn_curvature_registration_no_ref_ml.m
+def mf_nn_F(y, b, k, h_grid, mu, nu, sigma, conjugate_flag, nargout, reg):
+    """Local function F of the drivers (mf_nn_tv...:235-305; mf_nn_curvature...:230-291)."""
+    ncomp = 6 if reg == "tv" else 4
+    mn = y.size // (ncomp * k)
+    n2 = ncomp - 2
+    y1 = y[: k * mn]
+    y2 = y[k * mn: (n2 + 1) * k * mn]
+    y3 = y[(n2 + 1) * k * mn:]
+    hh = float(np.prod(h_grid))
+    if nargout == 3:
+        res3 = np.zeros(ncomp * k * mn)
+        res3[: k * mn] = px.SAD(y1, b, hh, sigma, conjugate_flag, 3)[2]
+        if reg == "tv":
+            Y2 = y2.reshape((4 * mn, k), order="F")
+            for j in range(k):
+                res3[k * mn + j * 4 * mn: k * mn + (j + 1) * 4 * mn] = \
+                    px.pointwise_2x2_nn(Y2[:, j], mu * hh, sigma, conjugate_flag, 3)[2]
+        else:
+            g0 = np.zeros(2 * k * mn)
+            res3[k * mn: 3 * k * mn] = px.SSD(y2, g0, mu * hh, sigma, conjugate_flag, 3)[2]
+        res3[(n2 + 1) * k * mn:] = px.nuclear_norm_constraint(y3, k, sigma, nu, conjugate_flag, 3)[2]
+        return None, None, res3
+    r1_F1, r2_F1, _ = px.SAD(y1, b, hh, sigma, conjugate_flag, 2)
+    if reg == "tv":
+        Y2 = y2.reshape((4 * mn, k), order="F")
+        r1_F2 = 0.0
+        r2_F2 = 0.0
+        for j in range(k):
+            a, c, _ = px.pointwise_2x2_nn(Y2[:, j], mu * hh, sigma, conjugate_flag, 2)
+            r1_F2 = r1_F2 + a
+            r2_F2 = max(r2_F2, c)
+    else:
+        g0 = np.zeros(2 * k * mn)
+        r1_F2, r2_F2, _ = px.SSD(y2, g0, mu * hh, sigma, conjugate_flag, 2)
+    r1_F3, r2_F3, _ = px.nuclear_norm_constraint(y3, k, sigma, nu, conjugate_flag, 2)
+    return np.array([r1_F1, r1_F2, r1_F3]), max(r2_F1, r2_F2, r2_F3), None
+
+
+def mf_nn_G(x, s, conjugate_flag, nargout):
+    """Local function G of the drivers (mf_nn_tv...:307-346)."""
+    N = int(np.prod(s))
+    x_u = x[: 2 * N]
+    x_l = x[2 * N:]
+    a1, c1, p1 = px.mean_zero_indicator(x_u, s, conjugate_flag, nargout)
+    a2, c2, p2 = px.zero_function(x_l, conjugate_flag, nargout)
+    if nargout == 3:
+        return None, None, np.concatenate([p1, p2])
+    return a1 + a2, max(c1, c2), None
+
+
+def mf_nn_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start, keep=None):
+    """[u, L, SV_history] = mf_nn_{tv,curvature}_registration_no_ref_ml(img, optPara).
+
+    `keep` (dict) receives diagnostics per (lev, o): nu, tau, norm estimate, histories.
+    The curvature driver returns only the last iterate (mf_nn_curvature...:8); here both return
+    the full cell arrays and the caller picks."""
+    k = len(img)
+    img = [normalize(im) for im in img]                                          # (:49-51)
+    m, n = img[0].shape
+    omega = [0.0, float(m), 0.0, float(n)]
+    numLevels = ops.num_levels(m, n)                                             # (:59)
+    max_outer = int(max(optPara["outerIter"]))
+    u = [[None] * max_outer for _ in range(numLevels)]
+    L = [[None] * max_outer for _ in range(numLevels)]
+    SV_history = [None] * numLevels
+    ML = [ops.pyramid(im, numLevels) for im in img]                              # ML[i][lev]
+    x = None
+    nu = None
+    ncomp = 6 if reg == "tv" else 4
+    for lev in range(numLevels):
+        m, n = ML[0][lev].shape
+        h_grid = np.array([(omega[1] - omega[0]) / m, (omega[3] - omega[2]) / n])   # (:88)
+        theta = optPara["theta"]
+        tol = optPara["tol"]
+        mu = optPara["mu"]
+        bc = optPara["bc"]
+        maxIter = optPara["maxIter"]
+        sel = 0 if lev == 0 else 1
+        outerIter = int(optPara["outerIter"][sel])
+        nu_factor = optPara["nu_factor"][sel]
+        if lev == 0:
+            x = np.zeros(3 * k * m * n)
+        else:
+            m_low, n_low = ML[0][lev - 1].shape
+            x = ops.prolong_fields(x, m_low, n_low, m, n, 3 * k)                 # (:111-119)
+        p = np.zeros(ncomp * k * m * n)                                          # (:122)
+        if reg == "tv":
+            A2 = ops.finite_difference_operator(m, n, h_grid, k, bc)
+        else:
+            A2 = ops.discrete_laplacian(m, n, h_grid, k, bc)
+        kmn = k * m * n
+        A3 = sp.csr_matrix((kmn, 2 * kmn))
+        A4 = sp.identity(kmn, format="csr")
+        A5 = sp.csr_matrix((A2.shape[0], kmn))
+        A6 = ops.mean_free_operator(m, n, k)
+        s = (m, n, k)
+        Gh = lambda xx, c, nargout: mf_nn_G(xx, s, c, nargout)
+        u0 = x[: 2 * kmn].reshape((m * n, 2, k), order="F")
+        SV_history[lev] = np.zeros((k, max_outer))
+        for o in range(outerIter):
+            b = np.zeros(kmn)
+            T_u = np.zeros((m, n, k))
+            dT = []
+            for i in range(k):
+                T_u[:, :, i], g = ops.evaluate_displacement(ML[i][lev], h_grid, u0[:, :, i], omega)
+                dT.append(ops.grad_matrix(g))
+                b[i * m * n: (i + 1) * m * n] = T_u[:, :, i].reshape(-1, order="F") - \
+                    dT[i] @ u0[:, :, i].reshape(-1, order="F")                   # (:167-168)
+            if o == 0 and lev == 0:
+                D = (A6 @ T_u.reshape(-1, order="F")).reshape((m * n, k), order="F")
+                S = np.linalg.svd(D, compute_uv=False)
+                nu = nu_factor * np.sum(S)                                       # (:173-175)
+            elif o == 0 and lev > 0:
+                nu = 2 * nu_factor * nu                                          # (:177)
+            else:
+                nu = nu_factor * nu                                              # (:179)
+            A1 = -sp.block_diag(dT, format="csr")
+            A = sp.bmat([[A1, A4], [A2, A5], [A3, A6]], format="csr")            # (:186-188)
+            e = ops.matrix_norm(A, normest_x0(A.shape[1]) if normest_x0 is not None else None)
+            norm_A_est = e[-1]
+            tau = np.sqrt(0.99 / norm_A_est ** 2)                                # (:195-196)
+            sigma = np.sqrt(0.99 / norm_A_est ** 2)
+            nu_ = nu
+            Fh = lambda y, c, nargout: mf_nn_F(y, b, k, h_grid, mu, nu_, sigma, c, nargout, reg)
+            x, p, ph, dh = chambolle_pock(Fh, Gh, A, x, p, theta, tau, sigma, maxIter, tol)
+            u0 = x[: 2 * kmn].reshape((m * n, 2, k), order="F")
+            L0 = x[2 * kmn:]
+            u[lev][o] = u0.copy()
+            L[lev][o] = L0.reshape((m, n, k), order="F").copy()
+            S = np.linalg.svd((A6 @ L0).reshape((m * n, k), order="F"), compute_uv=False)
+            SV_history[lev][:, o] = S                                            # (:214-215)
+            if keep is not None:
+                keep[(lev, o)] = dict(nu=nu, tau=tau, sigma=sigma, norm_est=norm_A_est, n_power=len(e),
+                                      primal_history=ph, dual_history=dh, p=p.copy(), x=x.copy(),
+                                      b=b.copy(), m=m, n=n)
+    return u, L, SV_history
+
+
+def mf_nn_problem(ML_lev, u0, h_grid, omega, reg, bc):
+    """Assemble (A, b, T_u, g) for one linearisation; helper for operator-level tests.
+    Mirrors mf_nn_tv...:159-188."""
+    k = len(ML_lev)
+    m, n = ML_lev[0].shape
+    kmn = k * m * n
+    b = np.zeros(kmn)
+    T_u = np.zeros((m, n, k))
+    dT = []
+    gs = []
+    for i in range(k):
+        T_u[:, :, i], g = ops.evaluate_displacement(ML_lev[i], h_grid, u0[:, :, i], omega)
+        gs.append(g)
+        dT.append(ops.grad_matrix(g))
+        b[i * m * n: (i + 1) * m * n] = T_u[:, :, i].reshape(-1, order="F") - dT[i] @ u0[:, :, i].reshape(-1, order="F")
+    if reg == "tv":
+        A2 = ops.finite_difference_operator(m, n, h_grid, k, bc)
+    else:
+        A2 = ops.discrete_laplacian(m, n, h_grid, k, bc)
+    A1 = -sp.block_diag(dT, format="csr")
+    A = sp.bmat([[A1, sp.identity(kmn)], [A2, sp.csr_matrix((A2.shape[0], kmn))],
+                 [sp.csr_matrix((kmn, 2 * kmn)), ops.mean_free_operator(m, n, k)]], format="csr")
+    return A, b, T_u, gs
