@@ -1,0 +1,164 @@
+/*
+ * cpengine.h -- C ABI of the MI355X-native Chambolle-Pock registration engine.
+ *
+ * This is the drop-in boundary for the primal-dual hot path of roland1993/MA: the
+ * reference's MATLAB entry points keep their signatures and call these functions
+ * through a MEX gateway.  Plain C, `int` status return
+ * (0 = ok), no exceptions cross the boundary, no torch types.
+ *
+ * Conventions
+ *   - host buffers are caller-owned, column-major (MATLAB layout), double;
+ *     inputs are never written, outputs go into caller-allocated buffers;
+ *   - device memory is owned by the handle and stays resident across CP
+ *     iterations and across outer (re-linearisation) iterations;
+ *   - a handle is not thread-safe: one handle per host thread;
+ *   - every entry point is synchronous on return unless stated otherwise.
+ *
+ * Vector layouts (identical to the reference):
+ *   pairwise models   x = [u_x(:); u_y(:)] (2mn)  or  u(:) (mn, denoise)
+ *                     y = [Dx u_x; Dy u_x; Dx u_y; Dy u_y] (4mn) or [Dx u; Dy u] (2mn)
+ *                     (PDO/test_TV_L1_registration.m:67-79)
+ *   mf_nn models      x = [u; L], u = per image [u_x,i(:); u_y,i(:)], L = k stacked images (3kmn)
+ *                     y = [y1 (kmn); y2 (4kmn TV | 2kmn curvature); y3 (kmn)]
+ *                     (NNE/mf_nn_tv_registration_no_ref_ml.m:150,246-248)
+ */
+#ifndef CPENGINE_H
+#define CPENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cp_engine *cp_handle;
+
+/* model = which (F, G, K) triple of the reference the handle solves */
+enum {
+    CP_MODEL_TV_L1_DENOISE = 1, /* F=TV_denoise,      G=SAD_denoise       PDO/test_TV_L1_denoising.m:58-59   */
+    CP_MODEL_TV_L1_REG     = 2, /* F=TV_registration, G=SAD_registration  PDO/test_TV_L1_registration.m:84-85 */
+    CP_MODEL_TV_L2_REG     = 3, /* F=TV_registration, G=SSD_registration  PDO/test_TV_L2_registration.m:84-85 */
+    CP_MODEL_MF_NN_TV      = 4, /* NNE/mf_nn_tv_registration_no_ref_ml.m:183-203,235-346          */
+    CP_MODEL_MF_NN_CURV    = 5  /* NNE/mf_nn_curvature_registration_no_ref_ml.m:182-202,230-332   */
+};
+
+/* boundary condition strings of the reference */
+enum {
+    CP_BC_NEUMANN   = 0, /* NNE/finite_difference_operator.m:33, NNE/discrete_laplacian.m:25-27 */
+    CP_BC_LINEAR    = 1, /* NNE/finite_difference_operator.m:31 (last row [-1 1], unscaled)      */
+    CP_BC_DIRICHLET = 2  /* NNE/discrete_laplacian.m:28                                          */
+};
+
+enum { CP_STOP_MAXITER = 0, CP_STOP_TOLERANCE = 1 }; /* PDO/chambolle_pock.m:137,145-153 */
+
+/* status codes; cp_last_error() holds the text (message ids cpengine:<name>) */
+enum {
+    CP_OK = 0,
+    CP_ERR_BAD_ARG = 1,      /* cpengine:badArg  */
+    CP_ERR_BAD_BC = 2,       /* cpengine:badBC   -- 'Unknown boundary condition!' finite_difference_operator.m:35 */
+    CP_ERR_BAD_STATE = 3,    /* cpengine:badState (e.g. solve before linearize) */
+    CP_ERR_DEVICE = 4,       /* cpengine:device  (HIP runtime error) */
+    CP_ERR_UNSUPPORTED = 5   /* cpengine:unsupported */
+};
+
+typedef struct cp_problem_desc {
+    int32_t model;      /* CP_MODEL_*                                                        */
+    int32_t m, n;       /* image rows, columns (column-major, rows contiguous)               */
+    int32_t k;          /* number of images (mf_nn models, 1..16); 1 for pairwise            */
+    int32_t bc;         /* CP_BC_* ; pairwise models always use neumann (script form)        */
+    int32_t device;     /* HIP device ordinal                                                */
+    int32_t batch;      /* number of independent problems of this shape in the handle (>=1)  */
+    int32_t reserved0;
+    double  h[2];       /* grid spacing h_grid = [h1, h2]                                    */
+    double  omega[4];   /* image region [w1,w2]x[w3,w4]; all zeros -> [0, m*h1, 0, n*h2]     */
+    double  lambda;     /* data-term weight of the pairwise models                           */
+    double  mu;         /* regulariser weight of the mf_nn models (optPara.mu)               */
+    /* row-slab decomposition along j (image columns); single GPU: n_global = n, j_offset = 0 */
+    int32_t n_global;   /* total number of image columns over all slabs                      */
+    int32_t j_offset;   /* global index of this slab's first column                          */
+} cp_problem_desc;
+
+typedef struct cp_result {
+    int32_t iterations;   /* i at exit of the loop, PDO/chambolle_pock.m:134-193            */
+    int32_t stop_reason;  /* CP_STOP_*                                                       */
+    int32_t rows;         /* history rows = iterations + 1                                   */
+    int32_t cols;         /* history columns (5 pairwise, 7 mf_nn), PDO/chambolle_pock.m:224-228 */
+} cp_result;
+
+/* --- life cycle ---------------------------------------------------------------------- */
+int cp_create(const cp_problem_desc *desc, cp_handle *out);
+int cp_destroy(cp_handle h);
+const char *cp_last_error(void);
+/* version string, also proves the library loads without touching a GPU */
+const char *cp_version(void);
+
+/* --- data in --------------------------------------------------------------------------
+ * cp_set_images: pairwise registration: a = template T, b = reference R (m x n each, already
+ *   normalised as PDO/test_TV_L1_registration.m:57-58); denoise: a = noisy image, b = NULL;
+ *   mf_nn: a = k stacked m x n images at this level (already normalised), b = NULL.
+ *   For batch > 1 the problems are stacked along the last dimension. In slab mode the FULL
+ *   images (n_global columns) are passed on every rank (warps need no communication).      */
+int cp_set_images(cp_handle h, const double *a, const double *b);
+/* start vectors x0 / y0 (chambolle_pock.m:82-84); NULL = zeros                             */
+int cp_set_primal(cp_handle h, const double *x0);
+int cp_set_dual(cp_handle h, const double *y0);
+
+/* --- linearisation  (replaces the evaluate_displacement call inside G / the driver) -----
+ * Warps the template(s) at u0 (NULL = the handle's current primal u, i.e. the warm start of
+ * the outer loop, PDO/test_TV_L1_registration.m:119-120 / NNE/mf_nn_tv...:164-169), stores
+ * grad T(u0) and b = T(u0) - grad T * u0 [- R].
+ * IRE/evaluate_displacement.m:38-49, IRE/bilinear_interpolation.m:29-105.                   */
+int cp_linearize(cp_handle h, const double *u0);
+/* copies of the linearisation for unit parity: T(u0) (m*n*k), grad (m*n x 2 per image), b  */
+int cp_get_linearization(cp_handle h, double *T_u, double *grad, double *b);
+
+/* --- mf_nn only --------------------------------------------------------------------------
+ * radius nu of the nuclear-norm ball (NNE/mf_nn_tv...:171-180 keeps the schedule on the host) */
+int cp_set_nu(cp_handle h, double nu);
+/* singular values (descending, k of them) of reshape(B*field, mn, k):
+ *   which = 0: field = T(u0) of the last cp_linearize   (nu_0, NNE/mf_nn_tv...:173-175)
+ *   which = 1: field = L part of the current primal x    (SV_history, :214-215)             */
+int cp_singular_values(cp_handle h, int which, double *sv);
+/* power iteration of NNE/matrix_norm.m:15-48 on the current block operator A. x0 = start
+ * vector (length 3kmn) or NULL for the engine's deterministic start
+ * x_i = ((i*2654435761) mod 2^32)/2^31 - 1. Returns e(end) and the number of iterations.    */
+int cp_norm_estimate(cp_handle h, const double *x0, double *est, int32_t *iters);
+
+/* --- solve: PDO/chambolle_pock.m:54-228 for the handle's (F, G, K) ----------------------- */
+int cp_solve(cp_handle h, double theta, double tau, double sigma, int32_t max_iter, double tol,
+             cp_result *res);
+/* primal_history / dual_history of the last solve, rows x cols column-major
+ * (PDO/chambolle_pock.m:224-228)                                                            */
+int cp_get_history(cp_handle h, double *primal_history, double *dual_history);
+
+/* result record of problem `problem` of a batch after the last cp_solve (0 for single problems)  */
+int cp_get_result(cp_handle h, int32_t problem, cp_result *res);
+
+/* --- data out ------------------------------------------------------------------------------ */
+int cp_get_primal(cp_handle h, double *x);
+int cp_get_dual(cp_handle h, double *y);
+/* the handle's template image(s) at this level (after cp_set_images / cp_downsample)           */
+int cp_get_images(cp_handle h, double *a);
+
+/* --- multi-level -----------------------------------------------------------------------------
+ * cp_prolong: x_fine = kron(x_coarse, ones(2)) cropped, all fields, times `factor`
+ * (NNE/mf_nn_tv...:113-119, factor 1; var drivers use 2, NNE/var_tv...:112); the dual of
+ * `fine` is reset to zero (:122).
+ * cp_downsample: 2x2 block mean with zero padding past the end, odd samples (:75-76); writes the
+ * images of `coarse` from those of `fine`.                                                   */
+int cp_prolong(cp_handle coarse, cp_handle fine, double factor);
+int cp_downsample(cp_handle fine, cp_handle coarse);
+
+/* --- benchmarking hooks (no counterpart in the reference) -----------------------------------
+ * cp_iterate runs `iters` full CP iterations (dual pass, eigensolve, primal pass, history row)
+ * asynchronously on the handle's stream with the stop rule disabled, without resetting the
+ * state; cp_sync waits for them. cp_kernel_time_ms returns the accumulated HIP-event time and
+ * launch count of the named pass ("dual", "primal", "eig", "fin") since the last call.       */
+int cp_iterate(cp_handle h, double theta, double tau, double sigma, int32_t iters);
+int cp_sync(cp_handle h);
+int cp_kernel_time_ms(cp_handle h, const char *pass, double *ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPENGINE_H */

@@ -1,0 +1,202 @@
+// Device-side building blocks shared by all cpengine kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CP_BLOCK 256          // threads per workgroup (4 waves)
+#define CP_WAVES (CP_BLOCK / 64)
+#define CP_KMAX 16            // max images per mf_nn problem (one 16x16 f64 MFMA tile)
+#define CP_TS 66              // LDS tile row stride (doubles): conflict-free ds_read_b64 in MFMA order
+#define CP_NSUM 8             // per-pass partial sums   (slots 0..7)
+#define CP_NMAX 8             // per-pass partial maxima (slots 8..15)
+#define CP_NSCAL (CP_NSUM + CP_NMAX)
+#define CP_PSTRIDE (CP_NSCAL + CP_KMAX * CP_KMAX)   // doubles per block in the partial buffer
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions (deterministic: fixed shuffle tree, fixed wave order)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// Reduce NS sums and NM maxima over the block; thread 0 writes them to out[0..NS+NM).
+// red: LDS scratch of at least CP_WAVES * (NS + NM) doubles.
+template <int NS, int NM>
+__device__ __forceinline__ void block_reduce_store(const double (&s)[NS], const double (&mx)[NM],
+                                                   double *red, double *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+        double v = wave_sum(s[a]);
+        if (lane == 0) red[wave * (NS + NM) + a] = v;
+    }
+#pragma unroll
+    for (int a = 0; a < NM; ++a) {
+        double v = wave_max(mx[a]);
+        if (lane == 0) red[wave * (NS + NM) + NS + a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS + NM) {
+        const int a = threadIdx.x;
+        double v = red[a];
+        for (int w = 1; w < CP_WAVES; ++w) {
+            const double o = red[w * (NS + NM) + a];
+            v = (a < NS) ? v + o : fmax(v, o);
+        }
+        out[a] = v;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram contraction on the matrix cores.
+// tile: wave-private LDS image [16][CP_TS]; tile[img][p] = value of image `img` at the wave's p-th
+// pixel (rows >= K and pixels past the end hold zeros).  Accumulates Y^T Y of the 64 x 16 block
+// into acc: acc[r] = G[(lane>>4) + 4r][lane&15]  (v_mfma_f64_16x16x4_f64 C/D layout).
+__device__ __forceinline__ void gram_tile_accum(const double *tile, double4_t &acc) {
+    const int lane = threadIdx.x & 63;
+    const double *src = tile + (lane & 15) * CP_TS + (lane >> 4);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const double v = src[4 * t];   // A[img][pix] == B[pix][img]: same register for both operands
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+    }
+}
+
+// Sum the 4 waves' Gram accumulators in fixed order and write the 256 entries to out[].
+// stage: LDS scratch of CP_WAVES*256 doubles.
+__device__ __forceinline__ void gram_block_store(const double4_t &acc, double *stage, double *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = (lane >> 4) + 4 * r, col = lane & 15;
+        stage[wave * 256 + row * 16 + col] = acc[r];
+    }
+    __syncthreads();
+    {
+        const int e = threadIdx.x;   // CP_BLOCK == 256 entries
+        double v = stage[e];
+        for (int w = 1; w < CP_WAVES; ++w) v += stage[w * 256 + e];
+        out[e] = v;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// cos/sin of atan2(y, x) / 2 without transcendentals (the angle lies in [-pi/2, pi/2]).
+// atan2(0, 0) = 0 as in MATLAB (NNE/svd_2x2.m:22,30).
+__device__ __forceinline__ void half_angle(double x, double y, double &c, double &s) {
+    const double r = sqrt(x * x + y * y);
+    if (r == 0.0) { c = 1.0; s = 0.0; return; }
+    const double inv2r = 0.5 / r;
+    if (x >= 0.0) {
+        c = sqrt((r + x) * inv2r);
+        s = y * inv2r / c;
+    } else {
+        s = copysign(sqrt((r - x) * inv2r), y);
+        c = y * inv2r / s;
+    }
+}
+
+// singular values of the 2x2 matrix [a b; c d] given as (a, c, b, d) = (m11, m21, m12, m22)
+// NNE/svd_2x2.m:15-20
+__device__ __forceinline__ void sv_2x2(double a, double c, double b, double d, double &sig1, double &sig2) {
+    const double aa = a * a, bb = b * b, cc = c * c, dd = d * d;
+    const double s1 = aa + bb + cc + dd;
+    const double xt = aa + bb - cc - dd;
+    const double acbd = a * c + b * d;
+    const double s2 = sqrt(xt * xt + 4.0 * (acbd * acbd));
+    sig1 = sqrt(fmax((s1 + s2) * 0.5, 0.0));
+    sig2 = sqrt(fmax((s1 - s2) * 0.5, 0.0));
+}
+
+__device__ __forceinline__ double sgn(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0); }
+
+// U * diag(max(Sigma - thr, 0)) * V' of the 2x2 matrix (a, c, b, d), following NNE/svd_2x2.m:22-47 and
+// NNE/pointwise_2x2_nn.m:16-24 (including the sign(0) = 0 columns of V in degenerate cases).
+__device__ __forceinline__ void svt_2x2(double a, double c, double b, double d, double thr,
+                                        double &r11, double &r21, double &r12, double &r22) {
+    const double aa = a * a, bb = b * b, cc = c * c, dd = d * d;
+    const double s1 = aa + bb + cc + dd;
+    const double xt = aa + bb - cc - dd;
+    const double yt = 2.0 * a * c + 2.0 * b * d;
+    const double acbd = a * c + b * d;
+    const double s2 = sqrt(xt * xt + 4.0 * (acbd * acbd));
+    const double sig1 = sqrt(fmax((s1 + s2) * 0.5, 0.0));
+    const double sig2 = sqrt(fmax((s1 - s2) * 0.5, 0.0));
+    const double t1 = fmax(sig1 - thr, 0.0), t2 = fmax(sig2 - thr, 0.0);
+    if (t1 == 0.0 && t2 == 0.0) { r11 = r21 = r12 = r22 = 0.0; return; }
+    double ct, st, cp, sp;
+    half_angle(xt, yt, ct, st);
+    const double xp = aa - bb + cc - dd;
+    const double yp = 2.0 * a * b + 2.0 * c * d;
+    half_angle(xp, yp, cp, sp);
+    // U = [u11 u21 u12 u22] = [ct st -st ct]
+    const double s11 = (a * ct + c * st) * cp + (b * ct + d * st) * sp;
+    const double s22 = (a * st - c * ct) * sp + (-b * st + d * ct) * cp;
+    const double g1 = sgn(s11), g2 = sgn(s22);
+    const double v11 = g1 * cp, v21 = g1 * sp, v12 = -g2 * sp, v22 = g2 * cp;
+    r11 = t1 * ct * v11 + t2 * (-st) * v12;
+    r21 = t1 * st * v11 + t2 * ct * v12;
+    r12 = t1 * ct * v21 + t2 * (-st) * v22;
+    r22 = t1 * st * v21 + t2 * ct * v22;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward difference along one axis with the reference's boundary rows
+// (NNE/finite_difference_operator.m:29-36): interior (u_next - u)/h; last row neumann 0,
+// linear u - u_prev (unscaled).
+__device__ __forceinline__ double fwd_diff(double u, double u_next, double u_prev, bool last, bool linear,
+                                           double inv_h) {
+    return last ? (linear ? (u - u_prev) : 0.0) : (u_next - u) * inv_h;
+}
+
+// adjoint of the above at position c of an axis with `len` entries: (D^T w)(c).
+// w_c = w(c), w_m = w(c-1), w_last = w(len-1).
+__device__ __forceinline__ double fwd_diff_adj(double w_c, double w_m, double w_last, int c, int len, bool linear,
+                                               double inv_h) {
+    double r = 0.0;
+    if (c >= 1) r += w_m * inv_h;
+    if (c <= len - 2) r -= w_c * inv_h;
+    if (linear) {
+        if (c == len - 2) r -= w_last;
+        if (c == len - 1) r += w_last;
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear interpolation with zero padding and its analytic derivatives at the world point (px, py)
+// (IRE/bilinear_interpolation.m:29-105). Coordinate arithmetic uses explicitly rounded (non-fused)
+// operations so that floor() -- the index logic -- is bit-identical to the CPU restatement.
+__device__ __forceinline__ void bilinear_tap(const double *__restrict__ img, int mi, int ni, double px, double py,
+                                             double inv_h1, double inv_h2, double &val, double &dx, double &dy) {
+    const double q1 = __dadd_rn(__dmul_rn(inv_h1, px), 0.5), q2 = __dadd_rn(__dmul_rn(inv_h2, py), 0.5);   // :29-35
+    const double f1 = floor(q1), f2 = floor(q2);                                                           // :42
+    const double c1 = q1 - f1, c2 = q2 - f2;                                                               // :64
+    val = 0.0; dx = 0.0; dy = 0.0;
+    // clamp before the int conversion: far out-of-domain samples have no valid tap anyway
+    const double lim = 1.0e9;
+    const long long s1 = (long long)fmin(fmax(f1, -lim), lim), s2 = (long long)fmin(fmax(f2, -lim), lim);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int di = t & 1, dj = t >> 1;
+        const long long si = s1 + di, sj = s2 + dj;                     // 1-based subscripts
+        if (si >= 1 && si <= mi && sj >= 1 && sj <= ni) {               // zero padding (:48-55)
+            const double v = img[(size_t)(sj - 1) * mi + (si - 1)];
+            const double w1 = di ? c1 : (1.0 - c1), w2 = dj ? c2 : (1.0 - c2);
+            val += w1 * w2 * v;
+            dx += inv_h1 * ((di ? 1.0 : -1.0) * w2) * v;                // :71-72,81-82,91-92,101-102
+            dy += inv_h2 * ((dj ? 1.0 : -1.0) * w1) * v;                // :74-75,84-85,94-95,104-105
+        }
+    }
+}
+

@@ -1,0 +1,879 @@
+// Host side of libcpengine.so: handle, device-resident state, solver loops, C ABI (include/cpengine.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cpengine.h"
+#include "cp_mfnn_small.cuh"
+#include "cp_pair.cuh"
+
+static thread_local std::string g_err;
+
+#define CP_FAIL(code, ...)                                   \
+    do {                                                     \
+        char buf_[512];                                      \
+        snprintf(buf_, sizeof buf_, __VA_ARGS__);            \
+        g_err = buf_;                                        \
+        return (code);                                       \
+    } while (0)
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            CP_FAIL(CP_ERR_DEVICE, "cpengine:device %s failed: %s (%s:%d)", #expr,               \
+                    hipGetErrorString(e_), __FILE__, __LINE__);                                  \
+    } while (0)
+
+#define CPCHK(expr)                  \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != CP_OK) return rc_; \
+    } while (0)
+
+enum { T_DUAL = 0, T_EIG, T_PRIMAL, T_FIN, T_ITER, T_COUNT };
+static const char *kPassNames[T_COUNT] = {"dual", "eig", "primal", "fin", "iterate"};
+
+struct PassTimer {
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+    size_t used = 0;              // events in use
+};
+
+struct cp_engine {
+    cp_problem_desc d;
+    bool mf = false;     // mf_nn model
+    int reg = 0;         // mf: 0 tv, 1 curvature
+    int gt = 0;          // pairwise: GT_*
+    int nc = 1;          // pairwise: components of u
+    int m = 0, nl = 0, K = 1, npix = 0, fs = 0, batch = 1;
+    int nxf = 0, npf = 0;   // fields per problem
+    size_t xN = 0, pN = 0;  // doubles per x / p buffer (all problems)
+    double *X[2] = {nullptr, nullptr}, *P[2] = {nullptr, nullptr};
+    double *g = nullptr, *b = nullptr, *Tu = nullptr, *img = nullptr, *imgR = nullptr;
+    double *W[3] = {nullptr, nullptr, nullptr};   // W[2] = scratch
+    double *xtmp = nullptr;
+    double *part = nullptr, *part2 = nullptr;     // per-block partials (mf: one; pw: dual / primal)
+    double *svout = nullptr;                      // k_mf_sv_eig output (16 + 256) + identity (256)
+    void *ctrl = nullptr;
+    double *hist_p = nullptr, *hist_d = nullptr;
+    int hist_rows = 0;   // rows allocated (per problem)
+    int hcols = 0;
+    int nblk = 0;
+    bool linearized = false, has_nu = false, has_images = false;
+    hipStream_t stream = nullptr;
+    std::vector<cp_result> last;   // per problem
+    bool profile = false;
+    PassTimer timers[T_COUNT];
+};
+
+// ------------------------------------------------------------------------------------------------
+static MfParams mf_params(const cp_engine *h, double theta, double tau, double sigma) {
+    MfParams P;
+    P.m = h->m; P.nl = h->nl; P.K = h->K; P.npix = h->npix;
+    P.n_global = h->d.n_global; P.j_off = h->d.j_offset; P.bc = h->d.bc; P.fs = h->fs;
+    P.inv_h1 = 1.0 / h->d.h[0]; P.inv_h2 = 1.0 / h->d.h[1];
+    P.mu1 = h->d.h[0] * h->d.h[1];              // prod(h_grid), NNE/mf_nn_tv...:257
+    P.mu2 = h->d.mu * (h->d.h[0] * h->d.h[1]);  // mu * prod(h_grid), :264
+    P.sigma = sigma; P.tau = tau; P.theta = theta;
+    P.invK = 1.0 / (double)h->K;
+    P.Ntot = (double)h->m * (double)h->d.n_global * (double)h->K;
+    return P;
+}
+
+static PwParams pw_params(const cp_engine *h, double theta, double tau, double sigma) {
+    PwParams P;
+    P.m = h->m; P.n = h->nl; P.npix = h->npix; P.fs = h->fs; P.nxf = h->nxf; P.nvf = h->npf;
+    P.inv_h1 = 1.0 / h->d.h[0]; P.inv_h2 = 1.0 / h->d.h[1];
+    P.sigma = sigma; P.tau = tau; P.theta = theta; P.lambda = h->d.lambda;
+    return P;
+}
+
+static int timer_begin(cp_engine *h, int which) {
+    if (!h->profile) return CP_OK;
+    PassTimer &t = h->timers[which];
+    if (t.used + 2 > t.ev.size()) {
+        for (int a = 0; a < 2; ++a) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            t.ev.push_back(e);
+        }
+    }
+    HIPCHK(hipEventRecord(t.ev[t.used], h->stream));
+    return CP_OK;
+}
+static int timer_end(cp_engine *h, int which) {
+    if (!h->profile) return CP_OK;
+    PassTimer &t = h->timers[which];
+    HIPCHK(hipEventRecord(t.ev[t.used + 1], h->stream));
+    t.used += 2;
+    return CP_OK;
+}
+
+// copy between the host vector layout (fields contiguous, m x nl each) and the device field layout
+static int upload_fields(cp_engine *h, double *dev, const double *host, int nfields) {
+    for (int f = 0; f < nfields; ++f) {
+        double *dst = dev + (size_t)f * h->fs + h->m;
+        if (host)
+            HIPCHK(hipMemcpyAsync(dst, host + (size_t)f * h->npix, sizeof(double) * h->npix, hipMemcpyHostToDevice,
+                                  h->stream));
+        else
+            HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * h->npix, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CP_OK;
+}
+static int download_fields(cp_engine *h, const double *dev, double *host, int nfields) {
+    for (int f = 0; f < nfields; ++f)
+        HIPCHK(hipMemcpyAsync(host + (size_t)f * h->npix, dev + (size_t)f * h->fs + h->m, sizeof(double) * h->npix,
+                              hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CP_OK;
+}
+
+static int ensure_hist(cp_engine *h, int rows) {
+    if (rows <= h->hist_rows) return CP_OK;
+    if (h->hist_p) HIPCHK(hipFree(h->hist_p));
+    if (h->hist_d) HIPCHK(hipFree(h->hist_d));
+    h->hist_p = h->hist_d = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)rows * h->hcols * h->batch;
+    HIPCHK(hipMalloc(&h->hist_p, bytes));
+    HIPCHK(hipMalloc(&h->hist_d, bytes));
+    h->hist_rows = rows;
+    return CP_OK;
+}
+
+static int grid_for(const cp_engine *h) {
+    const int need = (h->npix + CP_BLOCK - 1) / CP_BLOCK;
+    return std::max(1, std::min(need, 2048));
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" const char *cp_last_error(void) { return g_err.c_str(); }
+extern "C" const char *cp_version(void) { return "cpengine 0.1 (gfx950, fp64)"; }
+
+extern "C" int cp_destroy(cp_handle h) {
+    if (!h) return CP_OK;
+    hipSetDevice(h->d.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    double *ptrs[] = {h->X[0], h->X[1], h->P[0], h->P[1], h->g, h->b, h->Tu, h->img, h->imgR, h->W[0], h->W[1],
+                      h->W[2], h->xtmp, h->part, h->part2, h->svout, h->hist_p, h->hist_d};
+    for (double *p : ptrs)
+        if (p) hipFree(p);
+    if (h->ctrl) hipFree(h->ctrl);
+    for (auto &t : h->timers)
+        for (hipEvent_t e : t.ev) hipEventDestroy(e);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return CP_OK;
+}
+
+extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
+    if (!desc || !out) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null descriptor or output");
+    *out = nullptr;
+    const cp_problem_desc &d = *desc;
+    if (d.m < 2 || d.n < 2) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg image size %d x %d", d.m, d.n);
+    if (!(d.h[0] > 0.0) || !(d.h[1] > 0.0)) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg grid spacing must be positive");
+    const bool mf = (d.model == CP_MODEL_MF_NN_TV || d.model == CP_MODEL_MF_NN_CURV);
+    const bool pw = (d.model == CP_MODEL_TV_L1_DENOISE || d.model == CP_MODEL_TV_L1_REG || d.model == CP_MODEL_TV_L2_REG);
+    if (!mf && !pw) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg unknown model %d", d.model);
+    if (mf) {
+        if (d.k < 1 || d.k > CP_KMAX) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported k = %d (1..%d)", d.k, CP_KMAX);
+        if (d.model == CP_MODEL_MF_NN_TV && d.bc != CP_BC_NEUMANN && d.bc != CP_BC_LINEAR)
+            CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");   // finite_difference_operator.m:35
+        if (d.bc < 0 || d.bc > 2) CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");
+        if (d.batch > 1) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported batch > 1 for mf_nn models");
+    }
+    cp_engine *h = new cp_engine();
+    h->d = d;
+    if (h->d.batch < 1) h->d.batch = 1;
+    if (h->d.n_global <= 0) { h->d.n_global = d.n; h->d.j_offset = 0; }
+    if (h->d.omega[0] == 0.0 && h->d.omega[1] == 0.0 && h->d.omega[2] == 0.0 && h->d.omega[3] == 0.0) {
+        h->d.omega[1] = d.m * d.h[0];                     // IRE/evaluate_displacement.m:34-36
+        h->d.omega[3] = h->d.n_global * d.h[1];
+    }
+    if (pw && (h->d.n_global != d.n)) { delete h; CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported slabs for pairwise models"); }
+    h->mf = mf;
+    h->m = d.m; h->nl = d.n; h->npix = d.m * d.n; h->fs = d.m * (d.n + 2);
+    h->batch = h->d.batch;
+    if (mf) {
+        h->K = d.k;
+        h->reg = (d.model == CP_MODEL_MF_NN_TV) ? 0 : 1;
+        h->nxf = 3 * h->K;
+        h->npf = (h->reg == 0 ? 6 : 4) * h->K;
+        h->hcols = CP_HCOLS_MF;
+    } else {
+        h->K = 1;
+        h->gt = (d.model == CP_MODEL_TV_L1_REG) ? GT_SAD_REG : (d.model == CP_MODEL_TV_L2_REG ? GT_SSD_REG : GT_SAD_DEN);
+        h->nc = (h->gt == GT_SAD_DEN) ? 1 : 2;
+        h->nxf = h->nc;
+        h->npf = 2 * h->nc;
+        h->hcols = CP_HCOLS_PW;
+    }
+    h->last.assign(h->batch, cp_result{0, 0, 0, 0});
+    *out = h;   // from here on cp_destroy cleans up
+    int rc = CP_OK;
+    auto body = [&]() -> int {
+        HIPCHK(hipSetDevice(d.device));
+        HIPCHK(hipStreamCreate(&h->stream));
+        h->xN = (size_t)h->nxf * h->fs * h->batch;
+        h->pN = (size_t)h->npf * h->fs * h->batch;
+        for (int a = 0; a < 2; ++a) {
+            HIPCHK(hipMalloc(&h->X[a], sizeof(double) * h->xN));
+            HIPCHK(hipMalloc(&h->P[a], sizeof(double) * h->pN));
+            HIPCHK(hipMemsetAsync(h->X[a], 0, sizeof(double) * h->xN, h->stream));
+            HIPCHK(hipMemsetAsync(h->P[a], 0, sizeof(double) * h->pN, h->stream));
+        }
+        const size_t gN = (size_t)2 * h->K * h->fs * h->batch, bN = (size_t)h->K * h->fs * h->batch;
+        HIPCHK(hipMalloc(&h->g, sizeof(double) * gN));
+        HIPCHK(hipMalloc(&h->b, sizeof(double) * bN));
+        HIPCHK(hipMalloc(&h->Tu, sizeof(double) * bN));
+        HIPCHK(hipMemsetAsync(h->g, 0, sizeof(double) * gN, h->stream));
+        HIPCHK(hipMemsetAsync(h->b, 0, sizeof(double) * bN, h->stream));
+        HIPCHK(hipMemsetAsync(h->Tu, 0, sizeof(double) * bN, h->stream));
+        const size_t imgN = (size_t)h->K * h->m * h->d.n_global * h->batch;
+        HIPCHK(hipMalloc(&h->img, sizeof(double) * imgN));
+        if (!mf && h->gt != GT_SAD_DEN) HIPCHK(hipMalloc(&h->imgR, sizeof(double) * imgN));
+        h->nblk = grid_for(h);
+        if (mf) {
+            for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
+            HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
+            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)h->nblk * CP_PSTRIDE));
+            HIPCHK(hipMalloc(&h->svout, sizeof(double) * (16 + 256 + 256)));
+            HIPCHK(hipMalloc(&h->ctrl, sizeof(CpCtrl)));
+            HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(CpCtrl), h->stream));
+            hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1]);
+            hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[2],
+                               h->svout + 16 + 256);
+        } else {
+            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)h->nblk * PW_PSTRIDE * h->batch));
+            HIPCHK(hipMalloc(&h->part2, sizeof(double) * (size_t)h->nblk * PW_PSTRIDE * h->batch));
+            HIPCHK(hipMalloc(&h->ctrl, sizeof(PwCtrl) * h->batch));
+            HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(PwCtrl) * h->batch, h->stream));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+        return CP_OK;
+    };
+    rc = body();
+    if (rc != CP_OK) { cp_destroy(h); *out = nullptr; }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int cp_set_images(cp_handle h, const double *a, const double *b) {
+    if (!h || !a) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle or image");
+    HIPCHK(hipSetDevice(h->d.device));
+    const size_t imgN = (size_t)h->K * h->m * h->d.n_global * h->batch;
+    if (!h->mf && h->gt == GT_SAD_DEN) {
+        // the noisy image g plays the role of b (field layout), PDO/test_TV_L1_denoising.m:58
+        for (int pr = 0; pr < h->batch; ++pr)
+            HIPCHK(hipMemcpyAsync(h->b + (size_t)pr * h->fs + h->m, a + (size_t)pr * h->npix, sizeof(double) * h->npix,
+                                  hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->linearized = true;
+    } else {
+        HIPCHK(hipMemcpyAsync(h->img, a, sizeof(double) * imgN, hipMemcpyHostToDevice, h->stream));
+        if (!h->mf) {
+            if (!b) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg reference image R missing");
+            HIPCHK(hipMemcpyAsync(h->imgR, b, sizeof(double) * imgN, hipMemcpyHostToDevice, h->stream));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->linearized = false;
+    }
+    h->has_images = true;
+    return CP_OK;
+}
+
+static int set_state(cp_handle h, double *dev, const double *host, int nfields) {
+    if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    return upload_fields(h, dev, host, nfields * h->batch);
+}
+extern "C" int cp_set_primal(cp_handle h, const double *x0) { return set_state(h, h ? h->X[0] : nullptr, x0, h ? h->nxf : 0); }
+extern "C" int cp_set_dual(cp_handle h, const double *y0) { return set_state(h, h ? h->P[0] : nullptr, y0, h ? h->npf : 0); }
+extern "C" int cp_get_primal(cp_handle h, double *x) {
+    if (!h || !x) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle or buffer");
+    HIPCHK(hipSetDevice(h->d.device));
+    return download_fields(h, h->X[0], x, h->nxf * h->batch);
+}
+extern "C" int cp_get_dual(cp_handle h, double *y) {
+    if (!h || !y) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle or buffer");
+    HIPCHK(hipSetDevice(h->d.device));
+    return download_fields(h, h->P[0], y, h->npf * h->batch);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int cp_linearize(cp_handle h, const double *u0) {
+    if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    if (!h->mf && h->gt == GT_SAD_DEN) return CP_OK;   // nothing to linearise
+    if (!h->has_images) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_linearize before cp_set_images");
+    const double *xsrc = h->X[0];
+    if (u0) {
+        // development point given explicitly: stage it in the spare x buffer
+        const int nuf = h->mf ? 2 * h->K : 2;
+        if (h->mf) {
+            CPCHK(upload_fields(h, h->X[1], u0, nuf));
+        } else {
+            for (int pr = 0; pr < h->batch; ++pr)
+                for (int f = 0; f < 2; ++f)
+                    HIPCHK(hipMemcpyAsync(h->X[1] + ((size_t)pr * h->nxf + f) * h->fs + h->m,
+                                          u0 + ((size_t)pr * 2 + f) * h->npix, sizeof(double) * h->npix,
+                                          hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        xsrc = h->X[1];
+    }
+    if (h->mf) {
+        WarpParams W;
+        W.m = h->m; W.nl = h->nl; W.K = h->K; W.npix = h->npix; W.n_global = h->d.n_global; W.j_off = h->d.j_offset;
+        W.fs = h->fs; W.mi = h->m; W.ni = h->d.n_global; W.ifs = h->m * h->d.n_global;
+        W.om0 = h->d.omega[0]; W.om2 = h->d.omega[2];
+        W.hx = (h->d.omega[1] - h->d.omega[0]) / h->m;              // IRE/cell_centered_grid.m:21-22
+        W.hy = (h->d.omega[3] - h->d.omega[2]) / h->d.n_global;
+        W.inv_h1 = 1.0 / h->d.h[0]; W.inv_h2 = 1.0 / h->d.h[1];
+        const long long tot = (long long)h->npix * h->K;
+        const int grid = (int)((tot + CP_BLOCK - 1) / CP_BLOCK);
+        hipLaunchKernelGGL(k_mf_warp, dim3(grid), dim3(CP_BLOCK), 0, h->stream, W, h->img, xsrc, h->Tu, h->g, h->b);
+    } else {
+        PwWarpParams W;
+        W.m = h->m; W.n = h->nl; W.npix = h->npix; W.fs = h->fs; W.nxf = h->nxf;
+        W.hx = (h->d.omega[1] - h->d.omega[0]) / h->m;
+        W.hy = (h->d.omega[3] - h->d.omega[2]) / h->nl;
+        W.inv_h1 = 1.0 / h->d.h[0]; W.inv_h2 = 1.0 / h->d.h[1];
+        const int grid = (h->npix + CP_BLOCK - 1) / CP_BLOCK;
+        hipLaunchKernelGGL(k_pw_warp, dim3(grid, h->batch), dim3(CP_BLOCK), 0, h->stream, W, h->img, h->imgR, xsrc,
+                           h->Tu, h->g, h->b);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->linearized = true;
+    return CP_OK;
+}
+
+extern "C" int cp_get_linearization(cp_handle h, double *T_u, double *grad, double *b) {
+    if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState no linearisation yet");
+    if (T_u) CPCHK(download_fields(h, h->Tu, T_u, h->K * h->batch));
+    if (grad) CPCHK(download_fields(h, h->g, grad, 2 * h->K * h->batch));
+    if (b) CPCHK(download_fields(h, h->b, b, h->K * h->batch));
+    return CP_OK;
+}
+
+extern "C" int cp_set_nu(cp_handle h, double nu) {
+    if (!h || !h->mf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_set_nu needs an mf_nn handle");
+    if (!(nu > 0.0)) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg nu must be positive");
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipMemcpyAsync(&((CpCtrl *)h->ctrl)->nu, &nu, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->has_nu = true;
+    return CP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// singular values of reshape(B*field, mn, k): Gram -> Jacobi, then a second Gram in the rotated basis
+// (column norms are sums of squares, so small singular values keep their relative accuracy).
+extern "C" int cp_singular_values(cp_handle h, int which, double *sv) {
+    if (!h || !h->mf || !sv) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_singular_values needs an mf_nn handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    if (h->d.n_global != h->nl) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_singular_values on a slab");
+    const double *field;
+    if (which == 0) {
+        if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_singular_values(0) before cp_linearize");
+        field = h->Tu;
+    } else if (which == 1) {
+        field = h->X[0] + (size_t)2 * h->K * h->fs;
+    } else {
+        CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg which = %d", which);
+    }
+    MfParams P = mf_params(h, 1.0, 1.0, 1.0);
+    double *ident = h->svout + 16 + 256, *vout = h->svout + 16;
+    hipLaunchKernelGGL(k_mf_gram_field, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, field, ident, h->part);
+    hipLaunchKernelGGL(k_mf_sv_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, h->nblk, h->part, ident, h->svout);
+    // second pass in the rotated basis; W[2] (scratch) receives the rotation
+    HIPCHK(hipMemcpyAsync(h->W[2], vout, sizeof(double) * 256, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_mf_gram_field, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, field, h->W[2], h->part);
+    hipLaunchKernelGGL(k_mf_sv_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, h->nblk, h->part, h->W[2], h->svout);
+    HIPCHK(hipGetLastError());
+    double lam[16];
+    HIPCHK(hipMemcpyAsync(lam, h->svout, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> s(h->K);
+    for (int i = 0; i < h->K; ++i) s[i] = std::sqrt(std::max(lam[i], 0.0));
+    std::sort(s.begin(), s.end(), [](double a, double b) { return a > b; });
+    for (int i = 0; i < h->K; ++i) sv[i] = s[i];
+    return CP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int32_t *iters) {
+    if (!h || !h->mf || !est) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_norm_estimate needs an mf_nn handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_norm_estimate before cp_linearize");
+    if (h->d.n_global != h->nl) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_norm_estimate on a slab");
+    MfParams P = mf_params(h, 1.0, 1.0, 1.0);
+    double *xa = h->X[1], *xb = h->xtmp, *yb = h->P[1];   // spare buffers (state lives in X[0], P[0])
+    HIPCHK(hipMemsetAsync(xa, 0, sizeof(double) * h->xN, h->stream));
+    HIPCHK(hipMemsetAsync(xb, 0, sizeof(double) * h->xN, h->stream));
+    if (x0) CPCHK(upload_fields(h, xa, x0, h->nxf));
+    else hipLaunchKernelGGL(k_mf_hash_start, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa);
+    // ||x0||
+    std::vector<double> hp((size_t)h->nblk * CP_PSTRIDE);
+    auto sumsq_partials = [&](double &out) -> int {
+        HIPCHK(hipMemcpyAsync(hp.data(), h->part, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        double s = 0.0;
+        for (int bI = 0; bI < h->nblk; ++bI) s += hp[(size_t)bI * CP_PSTRIDE];
+        out = s;
+        return CP_OK;
+    };
+    double nrm2 = 0.0;
+    {
+        // reuse applyAT's reduction for ||x||^2 would need y; do it on the host once (start vector only)
+        std::vector<double> hx((size_t)h->npix * h->nxf);
+        CPCHK(download_fields(h, xa, hx.data(), h->nxf));
+        for (double v : hx) nrm2 += v * v;
+    }
+    double scale = 1.0 / std::sqrt(nrm2);                       // NNE/matrix_norm.m:23
+    const double tol = 1e-6;
+    const int maxIter = 100;
+    std::vector<double> e;
+    int i = 0;
+    while (i < 2 || std::fabs(e[i - 1] - e[i - 2]) > tol * e[i - 1]) {   // :25
+        ++i;
+        if (h->reg == 0) {
+            hipLaunchKernelGGL((k_mf_applyA<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa, scale, h->g, yb);
+            hipLaunchKernelGGL((k_mf_applyAT<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, yb, h->g, xb, h->part);
+        } else {
+            hipLaunchKernelGGL((k_mf_applyA<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa, scale, h->g, yb);
+            hipLaunchKernelGGL((k_mf_applyAT<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, yb, h->g, xb, h->part);
+        }
+        HIPCHK(hipGetLastError());
+        double ss;
+        CPCHK(sumsq_partials(ss));
+        const double normY = std::sqrt(ss);                     // :35
+        scale = 1.0 / normY;                                    // :38
+        std::swap(xa, xb);
+        e.push_back(std::sqrt(normY));                          // :40
+        if (i == maxIter) break;
+    }
+    // the spare buffers are scratch again; the dual spare must be zero-free of halo garbage -> clear
+    HIPCHK(hipMemsetAsync(h->P[1], 0, sizeof(double) * h->pN, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *est = e.back();
+    if (iters) *iters = i;
+    return CP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+static void launch_mf_dual(cp_engine *h, const MfParams &P, const double *xc, const double *xo, const double *pin,
+                           double *pout, const double *W, int cc, int co) {
+    if (h->reg == 0)
+        hipLaunchKernelGGL((k_mf_dual<MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout, h->g,
+                           h->b, W, (const CpCtrl *)h->ctrl, cc, co, h->part);
+    else
+        hipLaunchKernelGGL((k_mf_dual<MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout, h->g,
+                           h->b, W, (const CpCtrl *)h->ctrl, cc, co, h->part);
+}
+template <int MODE>
+static void launch_mf_primal(cp_engine *h, const MfParams &P, const double *xc, double *xn, const double *p,
+                             const double *W, int cc) {
+    if (h->reg == 0)
+        hipLaunchKernelGGL((k_mf_primal<MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g, W,
+                           (const CpCtrl *)h->ctrl, cc, h->part);
+    else
+        hipLaunchKernelGGL((k_mf_primal<MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g, W,
+                           (const CpCtrl *)h->ctrl, cc, h->part);
+}
+
+static EigArgs eig_args(const cp_engine *h, const MfParams &P, int rp, int rd, int check, int update, int newbuf,
+                        double tol, int monitor = 0) {
+    EigArgs A;
+    A.monitor = monitor;
+    A.nblk = h->nblk; A.K = h->K; A.reg = h->reg; A.rp = rp; A.rd = rd; A.check_stop = check; A.update = update;
+    A.newbuf = newbuf; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2; A.sigma = P.sigma; A.Ntot = P.Ntot;
+    return A;
+}
+
+// iterations n = n0+1 .. n0+count of PDO/chambolle_pock.m:156-179 (state parity follows n)
+static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int check, double tol) {
+    CpCtrl *ctrl = (CpCtrl *)h->ctrl;
+    for (int n = n0 + 1; n <= n0 + count; ++n) {
+        const int cur = (n - 1) & 1, nxt = n & 1;
+        CPCHK(timer_begin(h, T_DUAL));
+        launch_mf_dual<0>(h, P, h->X[cur], h->X[nxt], h->P[cur], h->P[nxt], h->W[cur], cur, nxt);
+        CPCHK(timer_end(h, T_DUAL));
+        CPCHK(timer_begin(h, T_EIG));
+        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, eig_args(h, P, n - 1, n, check, 0, 0, tol),
+                           h->part, ctrl, h->W[nxt], h->hist_p, h->hist_d);
+        CPCHK(timer_end(h, T_EIG));
+        CPCHK(timer_begin(h, T_PRIMAL));
+        launch_mf_primal<0>(h, P, h->X[cur], h->X[nxt], h->P[nxt], h->W[nxt], cur);
+        CPCHK(timer_end(h, T_PRIMAL));
+        CPCHK(timer_begin(h, T_FIN));
+        hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_BLOCK), 0, h->stream, eig_args(h, P, n, n, 0, 1, nxt, tol),
+                           h->part, ctrl, h->hist_p, h->hist_d);
+        CPCHK(timer_end(h, T_FIN));
+    }
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+
+static int mf_begin(cp_engine *h) {
+    CpCtrl *ctrl = (CpCtrl *)h->ctrl;
+    hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, ctrl, h->W[0], h->W[1]);
+    HIPCHK(hipMemcpyAsync(h->X[1], h->X[0], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));   // x_old = x0
+    return CP_OK;
+}
+
+static int mf_end(cp_engine *h, const MfParams &P, int iterations) {
+    const int fb = iterations & 1;
+    if (h->reg == 0)
+        hipLaunchKernelGGL((k_mf_materialize<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[fb], h->X[0],
+                           h->P[fb], h->P[0], h->W[fb], (const CpCtrl *)h->ctrl, fb);
+    else
+        hipLaunchKernelGGL((k_mf_materialize<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[fb], h->X[0],
+                           h->P[fb], h->P[0], h->W[fb], (const CpCtrl *)h->ctrl, fb);
+    hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1]);
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+
+static int solve_mf(cp_engine *h, double theta, double tau, double sigma, int maxIter, double tol, cp_result *res) {
+    if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_solve before cp_linearize");
+    if (!h->has_nu) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_solve before cp_set_nu");
+    CPCHK(ensure_hist(h, maxIter + 2));
+    const MfParams P = mf_params(h, theta, tau, sigma);
+    CpCtrl *ctrl = (CpCtrl *)h->ctrl;
+    HIPCHK(hipMemsetAsync(h->hist_p, 0, sizeof(double) * (size_t)h->hist_rows * h->hcols, h->stream));
+    HIPCHK(hipMemsetAsync(h->hist_d, 0, sizeof(double) * (size_t)h->hist_rows * h->hcols, h->stream));
+    CPCHK(mf_begin(h));
+    // row 0: primal_objective(x0), dual_objective(y0)          chambolle_pock.m:89-106
+    launch_mf_dual<1>(h, P, h->X[0], h->X[1], h->P[0], nullptr, h->W[0], 0, 1);
+    hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, eig_args(h, P, 0, 0, 0, 0, 0, tol, 1), h->part, ctrl,
+                       h->W[2], h->hist_p, h->hist_d);
+    launch_mf_primal<1>(h, P, h->X[0], nullptr, h->P[0], h->W[0], 0);
+    hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_BLOCK), 0, h->stream, eig_args(h, P, 0, 0, 0, 0, 0, tol), h->part, ctrl,
+                       h->hist_p, h->hist_d);
+    HIPCHK(hipGetLastError());
+    int done = 0, stopped = 0, stop_iter = -1;
+    const int chunk = 32;
+    while (done < maxIter && !stopped) {
+        const int cnt = std::min(chunk, maxIter - done);
+        CPCHK(mf_iterations(h, P, done, cnt, 1, tol));
+        done += cnt;
+        int hdr[2];
+        HIPCHK(hipMemcpyAsync(hdr, ctrl, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        stopped = hdr[0];
+        stop_iter = hdr[1];
+    }
+    if (!stopped) {
+        // primal row maxIter (trails by one kernel) -- and the stop rule may still fire for i = maxIter? No:
+        // the reference breaks on i == maxIter before evaluating the rule (chambolle_pock.m:137).
+        const int cur = maxIter & 1;
+        launch_mf_dual<1>(h, P, h->X[cur], h->X[cur ^ 1], h->P[cur], nullptr, h->W[cur], cur, cur ^ 1);
+        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, eig_args(h, P, maxIter, -1, 0, 0, 0, tol),
+                           h->part, ctrl, h->W[2], h->hist_p, h->hist_d);
+        HIPCHK(hipGetLastError());
+    }
+    const int iterations = stopped ? stop_iter : maxIter;
+    // un-stop so that the canonicalisation kernels run
+    if (stopped) {
+        int zero = 0;
+        HIPCHK(hipMemcpyAsync(ctrl, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    CPCHK(mf_end(h, P, iterations));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->last[0] = cp_result{iterations, stopped ? CP_STOP_TOLERANCE : CP_STOP_MAXITER, iterations + 1, h->hcols};
+    if (res) *res = h->last[0];
+    return CP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+static void launch_pw_dual(cp_engine *h, const PwParams &P, const double *xc, const double *xo, const double *vin,
+                           double *vout) {
+    dim3 grid(h->nblk, h->batch);
+    if (h->nc == 2)
+        hipLaunchKernelGGL((k_pw_dual<MODE, 2>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xo, vin, vout,
+                           (const PwCtrl *)h->ctrl, h->part);
+    else
+        hipLaunchKernelGGL((k_pw_dual<MODE, 1>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xo, vin, vout,
+                           (const PwCtrl *)h->ctrl, h->part);
+}
+template <int MODE>
+static void launch_pw_primal(cp_engine *h, const PwParams &P, const double *xc, double *xn, const double *v) {
+    dim3 grid(h->nblk, h->batch);
+    const PwCtrl *ctrl = (const PwCtrl *)h->ctrl;
+    if (h->gt == GT_SAD_REG)
+        hipLaunchKernelGGL((k_pw_primal<MODE, GT_SAD_REG>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xn, v, h->g, h->b,
+                           ctrl, h->part2);
+    else if (h->gt == GT_SSD_REG)
+        hipLaunchKernelGGL((k_pw_primal<MODE, GT_SSD_REG>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xn, v, h->g, h->b,
+                           ctrl, h->part2);
+    else
+        hipLaunchKernelGGL((k_pw_primal<MODE, GT_SAD_DEN>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xn, v, h->b, h->b,
+                           ctrl, h->part2);
+}
+static PwFinArgs pw_fin_args(const cp_engine *h, int rpF, int rpG, int rd, int check, double tol) {
+    PwFinArgs A;
+    A.nblk = h->nblk; A.gt = h->gt; A.rpF = rpF; A.rpG = rpG; A.rd = rd; A.check_stop = check;
+    A.hist_rows = h->hist_rows; A.tol = tol; A.lambda = h->d.lambda;
+    return A;
+}
+static int pw_iterations(cp_engine *h, const PwParams &P, int n0, int count, int check, double tol) {
+    PwCtrl *ctrl = (PwCtrl *)h->ctrl;
+    for (int n = n0 + 1; n <= n0 + count; ++n) {
+        const int cur = (n - 1) & 1, nxt = n & 1;
+        CPCHK(timer_begin(h, T_DUAL));
+        launch_pw_dual<0>(h, P, h->X[cur], h->X[nxt], h->P[cur], h->P[nxt]);
+        CPCHK(timer_end(h, T_DUAL));
+        CPCHK(timer_begin(h, T_PRIMAL));
+        launch_pw_primal<0>(h, P, h->X[cur], h->X[nxt], h->P[nxt]);
+        CPCHK(timer_end(h, T_PRIMAL));
+        CPCHK(timer_begin(h, T_FIN));
+        hipLaunchKernelGGL(k_pw_fin, dim3(h->batch), dim3(64), 0, h->stream, pw_fin_args(h, n - 1, n, n, check, tol),
+                           h->part, h->part2, ctrl, h->hist_p, h->hist_d);
+        CPCHK(timer_end(h, T_FIN));
+    }
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+
+static int solve_pw(cp_engine *h, double theta, double tau, double sigma, int maxIter, double tol, cp_result *res) {
+    if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_solve before cp_linearize / cp_set_images");
+    CPCHK(ensure_hist(h, maxIter + 2));
+    const PwParams P = pw_params(h, theta, tau, sigma);
+    PwCtrl *ctrl = (PwCtrl *)h->ctrl;
+    const size_t hbytes = sizeof(double) * (size_t)h->hist_rows * h->hcols * h->batch;
+    HIPCHK(hipMemsetAsync(h->hist_p, 0, hbytes, h->stream));
+    HIPCHK(hipMemsetAsync(h->hist_d, 0, hbytes, h->stream));
+    HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(PwCtrl) * h->batch, h->stream));
+    HIPCHK(hipMemcpyAsync(h->X[1], h->X[0], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));
+    // row 0
+    launch_pw_dual<1>(h, P, h->X[0], h->X[1], h->P[0], nullptr);
+    launch_pw_primal<1>(h, P, h->X[0], nullptr, h->P[0]);
+    hipLaunchKernelGGL(k_pw_fin, dim3(h->batch), dim3(64), 0, h->stream, pw_fin_args(h, 0, 0, 0, 0, tol), h->part,
+                       h->part2, ctrl, h->hist_p, h->hist_d);
+    HIPCHK(hipGetLastError());
+    std::vector<PwCtrl> hc(h->batch);
+    int done = 0;
+    bool all_stopped = false;
+    const int chunk = 32;
+    while (done < maxIter && !all_stopped) {
+        const int cnt = std::min(chunk, maxIter - done);
+        CPCHK(pw_iterations(h, P, done, cnt, 1, tol));
+        done += cnt;
+        HIPCHK(hipMemcpyAsync(hc.data(), ctrl, sizeof(PwCtrl) * h->batch, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        all_stopped = true;
+        for (auto &c : hc) all_stopped = all_stopped && c.stop;
+    }
+    // F part of primal row maxIter for the problems that ran to the end (stopped ones skip the kernels)
+    {
+        const int cur = maxIter & 1;
+        launch_pw_dual<1>(h, P, h->X[cur], h->X[cur ^ 1], h->P[cur], nullptr);
+        hipLaunchKernelGGL(k_pw_fin, dim3(h->batch), dim3(64), 0, h->stream, pw_fin_args(h, maxIter, -1, -1, 0, tol),
+                           h->part, h->part2, ctrl, h->hist_p, h->hist_d);
+        HIPCHK(hipGetLastError());
+    }
+    // canonical state: result of problem pr lives in buffer (iterations & 1) -> copy into buffer 0
+    for (int pr = 0; pr < h->batch; ++pr) {
+        const int it = hc[pr].stop ? hc[pr].stop_iter : maxIter;
+        h->last[pr] = cp_result{it, hc[pr].stop ? CP_STOP_TOLERANCE : CP_STOP_MAXITER, it + 1, h->hcols};
+        if (it & 1) {
+            HIPCHK(hipMemcpyAsync(h->X[0] + (size_t)pr * h->nxf * h->fs, h->X[1] + (size_t)pr * h->nxf * h->fs,
+                                  sizeof(double) * h->nxf * h->fs, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->P[0] + (size_t)pr * h->npf * h->fs, h->P[1] + (size_t)pr * h->npf * h->fs,
+                                  sizeof(double) * h->npf * h->fs, hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (res) *res = h->last[0];
+    return CP_OK;
+}
+
+extern "C" int cp_solve(cp_handle h, double theta, double tau, double sigma, int32_t max_iter, double tol,
+                        cp_result *res) {
+    if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    if (max_iter < 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg max_iter < 0");
+    if (!(tau > 0.0) || !(sigma > 0.0)) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg step sizes must be positive");
+    HIPCHK(hipSetDevice(h->d.device));
+    return h->mf ? solve_mf(h, theta, tau, sigma, max_iter, tol, res) : solve_pw(h, theta, tau, sigma, max_iter, tol, res);
+}
+
+extern "C" int cp_get_result(cp_handle h, int32_t problem, cp_result *res) {
+    if (!h || !res || problem < 0 || problem >= h->batch) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_get_result");
+    *res = h->last[problem];
+    return CP_OK;
+}
+
+extern "C" int cp_get_history(cp_handle h, double *primal_history, double *dual_history) {
+    if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    if (h->hist_rows == 0) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState no solve yet");
+    // device: [problem][row][col]; host: per problem rows x cols column-major, problems stacked
+    std::vector<double> tmp((size_t)h->hist_rows * h->hcols * h->batch);
+    for (int which = 0; which < 2; ++which) {
+        double *dst = which ? dual_history : primal_history;
+        if (!dst) continue;
+        HIPCHK(hipMemcpy(tmp.data(), which ? h->hist_d : h->hist_p, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+        size_t off = 0;
+        for (int pr = 0; pr < h->batch; ++pr) {
+            const int rows = h->last[pr].rows;
+            const double *src = tmp.data() + (size_t)pr * h->hist_rows * h->hcols;
+            for (int c = 0; c < h->hcols; ++c)
+                for (int r = 0; r < rows; ++r) dst[off + (size_t)c * rows + r] = src[(size_t)r * h->hcols + c];
+            off += (size_t)rows * h->hcols;
+        }
+    }
+    return CP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_prolong(int m, int n, int fs, int ml, int nlw, int fsl, int nfields, double factor,
+                          const double *__restrict__ xl, double *__restrict__ xh) {
+    const long long tot = (long long)m * n * nfields;
+    for (long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot; gid += (long long)gridDim.x * CP_BLOCK) {
+        const int f = (int)(gid / ((long long)m * n)), q = (int)(gid - (long long)f * m * n);
+        const int j = q / m, i = q - j * m;
+        // kron(x_low, ones(2)) cropped to (1:m, 1:n)          NNE/mf_nn_tv...:113-119
+        xh[(size_t)f * fs + m + q] = factor * xl[(size_t)f * fsl + ml + (size_t)(j >> 1) * ml + (i >> 1)];
+    }
+}
+
+extern "C" int cp_prolong(cp_handle coarse, cp_handle fine, double factor) {
+    if (!coarse || !fine) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    if (coarse->nxf != fine->nxf || coarse->batch != fine->batch || coarse->d.device != fine->d.device)
+        CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg handles do not match");
+    if (fine->m > 2 * coarse->m || fine->nl > 2 * coarse->nl)
+        CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg fine level larger than twice the coarse level");
+    HIPCHK(hipSetDevice(fine->d.device));
+    HIPCHK(hipStreamSynchronize(coarse->stream));
+    const int nf = fine->nxf * fine->batch;
+    hipLaunchKernelGGL(k_prolong, dim3(2048), dim3(CP_BLOCK), 0, fine->stream, fine->m, fine->nl, fine->fs, coarse->m,
+                       coarse->nl, coarse->fs, nf, factor, coarse->X[0], fine->X[0]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(fine->P[0], 0, sizeof(double) * fine->pN, fine->stream));   // p = zeros (:122)
+    HIPCHK(hipStreamSynchronize(fine->stream));
+    return CP_OK;
+}
+
+__global__ void k_downsample(int m, int n, int mc, int ncw, int nimg, const double *__restrict__ fimg,
+                             double *__restrict__ cimg) {
+    const long long tot = (long long)mc * ncw * nimg;
+    for (long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot; gid += (long long)gridDim.x * CP_BLOCK) {
+        const int f = (int)(gid / ((long long)mc * ncw)), q = (int)(gid - (long long)f * mc * ncw);
+        const int j = q / mc, i = q - j * mc;
+        const double *src = fimg + (size_t)f * m * n;
+        const int i0 = 2 * i, j0 = 2 * j;
+        // conv2(., 0.25*ones(2), 'same')(1:2:end, 1:2:end): zero padding past the end    NNE/mf_nn_tv...:75-76
+        const double a = src[(size_t)j0 * m + i0];
+        const double b = (i0 + 1 < m) ? src[(size_t)j0 * m + i0 + 1] : 0.0;
+        const double c = (j0 + 1 < n) ? src[(size_t)(j0 + 1) * m + i0] : 0.0;
+        const double d = (i0 + 1 < m && j0 + 1 < n) ? src[(size_t)(j0 + 1) * m + i0 + 1] : 0.0;
+        cimg[(size_t)f * mc * ncw + q] = 0.25 * a + 0.25 * b + 0.25 * c + 0.25 * d;
+    }
+}
+
+extern "C" int cp_downsample(cp_handle fine, cp_handle coarse) {
+    if (!coarse || !fine) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    if (!fine->has_images) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState fine level has no images");
+    const int mc = (fine->m + 1) / 2, ncw = (fine->d.n_global + 1) / 2;
+    if (coarse->m != mc || coarse->d.n_global != ncw || coarse->K != fine->K || coarse->batch != fine->batch)
+        CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg coarse level must be ceil(size/2)");
+    HIPCHK(hipSetDevice(fine->d.device));
+    const int nimg = fine->K * fine->batch;
+    hipLaunchKernelGGL(k_downsample, dim3(2048), dim3(CP_BLOCK), 0, fine->stream, fine->m, fine->d.n_global, mc, ncw, nimg,
+                       fine->img, coarse->img);
+    if (fine->imgR && coarse->imgR)
+        hipLaunchKernelGGL(k_downsample, dim3(2048), dim3(CP_BLOCK), 0, fine->stream, fine->m, fine->d.n_global, mc, ncw,
+                           nimg, fine->imgR, coarse->imgR);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(fine->stream));
+    coarse->has_images = true;
+    coarse->linearized = false;
+    return CP_OK;
+}
+
+extern "C" int cp_get_images(cp_handle h, double *a) {
+    if (!h || !a) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle or buffer");
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipMemcpy(a, h->img, sizeof(double) * (size_t)h->K * h->m * h->d.n_global * h->batch, hipMemcpyDeviceToHost));
+    return CP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int cp_iterate(cp_handle h, double theta, double tau, double sigma, int32_t iters) {
+    if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_iterate before cp_linearize");
+    CPCHK(ensure_hist(h, iters + 2));
+    h->profile = true;
+    if (h->mf) {
+        if (!h->has_nu) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_iterate before cp_set_nu");
+        const MfParams P = mf_params(h, theta, tau, sigma);
+        CPCHK(mf_begin(h));
+        PassTimer &t = h->timers[T_ITER];
+        if (t.used + 2 > t.ev.size())
+            for (int a = 0; a < 2; ++a) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); t.ev.push_back(e); }
+        HIPCHK(hipEventRecord(t.ev[t.used], h->stream));
+        CPCHK(mf_iterations(h, P, 0, iters, 0, 0.0));
+        HIPCHK(hipEventRecord(t.ev[t.used + 1], h->stream));
+        t.used += 2;
+        CPCHK(mf_end(h, P, iters));
+    } else {
+        const PwParams P = pw_params(h, theta, tau, sigma);
+        HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(PwCtrl) * h->batch, h->stream));
+        HIPCHK(hipMemcpyAsync(h->X[1], h->X[0], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));
+        PassTimer &t = h->timers[T_ITER];
+        if (t.used + 2 > t.ev.size())
+            for (int a = 0; a < 2; ++a) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); t.ev.push_back(e); }
+        HIPCHK(hipEventRecord(t.ev[t.used], h->stream));
+        CPCHK(pw_iterations(h, P, 0, iters, 0, 0.0));
+        HIPCHK(hipEventRecord(t.ev[t.used + 1], h->stream));
+        t.used += 2;
+        if (iters & 1) {
+            HIPCHK(hipMemcpyAsync(h->X[0], h->X[1], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->P[0], h->P[1], sizeof(double) * h->pN, hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    h->profile = false;
+    return CP_OK;
+}
+
+extern "C" int cp_sync(cp_handle h) {
+    if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CP_OK;
+}
+
+extern "C" int cp_kernel_time_ms(cp_handle h, const char *pass, double *ms, int64_t *launches) {
+    if (!h || !pass || !ms) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_kernel_time_ms");
+    HIPCHK(hipSetDevice(h->d.device));
+    int which = -1;
+    for (int a = 0; a < T_COUNT; ++a)
+        if (strcmp(pass, kPassNames[a]) == 0) which = a;
+    if (which < 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg unknown pass '%s'", pass);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    PassTimer &t = h->timers[which];
+    double tot = 0.0;
+    for (size_t a = 0; a + 1 < t.used; a += 2) {
+        float f = 0.f;
+        HIPCHK(hipEventElapsedTime(&f, t.ev[a], t.ev[a + 1]));
+        tot += f;
+    }
+    *ms = tot;
+    if (launches) *launches = (int64_t)(t.used / 2);
+    t.used = 0;
+    return CP_OK;
+}

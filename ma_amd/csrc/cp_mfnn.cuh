@@ -1,0 +1,388 @@
+// Fused Chambolle-Pock passes for the mf_nn (multi-image, nuclear-norm) models.
+//
+// One CP iteration of NNE/mf_nn_{tv,curvature}_registration_no_ref_ml.m with PDO/chambolle_pock.m:156-179
+// is executed as   k_mf_dual -> k_mf_eig -> k_mf_primal -> k_mf_fin :
+//
+//   k_mf_dual    y  <- prox_{sigma F*}(y + sigma*A*xbar)   (:162) for y1 (SAD*), y2 (pointwise 2x2 nn* | SSD*)
+//                and the un-projected y3~ = y3 + sigma*B*Lbar together with its K x K Gram matrix (MFMA);
+//                also the primal monitors F1(Ax), F2(Ax), mean(u) of the CURRENT x (they need neighbours /
+//                the mean offset of x and therefore trail the primal pass by one kernel).
+//   k_mf_eig     eig(Gram) -> singular values -> l1-ball projection -> W with y3 = y3~ * W (applied lazily by
+//                the readers of y3~), F3*; completes primal row n-1 / dual row n; evaluates the stop rule.
+//   k_mf_primal  x  <- prox_{tau G}(x - tau*A'*y)           (:165); the mean-zero projection is kept as a
+//                pending scalar offset c (true u = stored - c); Gram(B*L_new) and the G* monitors.
+//   k_mf_fin     offsets c, nuclear-norm feasibility of B*L, G* measures, completes dual row n.
+//
+// Data layout: every field is an m x nl column-major slab with one halo column on each side
+// (field stride fs = m*(nl+2), element (i,j) at fs*field + m*(j+1) + i).
+// x buffers: fields [2k+0]=u_x,k  [2k+1]=u_y,k  [2K+k]=L_k.
+// p buffers: fields [k]=y1_k ; TV: [K+4k+c]=y2_k,c (c: Dx u_x, Dy u_x, Dx u_y, Dy u_y), [5K+k]=y3_k
+//                              curv: [K+2k+c]=y2_k,c (c: Lap u_x, Lap u_y),            [3K+k]=y3_k
+#pragma once
+#include "cp_device.cuh"
+
+struct CpCtrl {
+    int stop;          // set by the stop rule; every later kernel of the solve returns immediately
+    int stop_iter;     // i at which the rule fired
+    int pad0, pad1;
+    double c[2][2];    // pending mean offsets of the two x buffers: true u = stored - c[buf][comp]
+    double nu;         // radius of the nuclear-norm ball
+    double sv[CP_KMAX];      // last singular values computed by k_mf_eig (descending not guaranteed)
+    double svL[CP_KMAX];     // last singular values of B*L computed by k_mf_fin
+};
+
+struct MfParams {
+    int m, nl, K, npix;
+    int n_global, j_off;
+    int bc;
+    int fs;
+    double inv_h1, inv_h2;
+    double mu1, mu2;          // h1*h2, mu*h1*h2
+    double sigma, tau, theta;
+    double invK, Ntot;
+};
+
+// slots of the per-block partial buffer
+enum { DS_F1 = 0, DS_F2, DS_F1S, DS_UX, DS_UY, DS_F2S };                 // dual pass sums
+enum { DM_Y1 = CP_NSUM, DM_S1 };                                          // dual pass maxima
+enum { PS_UX = 0, PS_UY, PS_WX };                                         // primal pass sums
+enum { PM_WXMAX = CP_NSUM, PM_WXMIN, PM_WYMAX, PM_WYMIN, PM_VL };         // primal pass maxima
+
+// y3 = y3~ * W for the wave's pixel: loads the K stored values, multiplies by the K x K matrix W (uniform,
+// scalar loads) and leaves the result in tile[k][lane]; returns sum_k y3[k].
+__device__ __forceinline__ double load_y3_apply_W(const double *__restrict__ y3base, int fs, int e, bool valid,
+                                                  int K, const double *__restrict__ W, double *tile, int lane) {
+    double t3[CP_KMAX];
+#pragma unroll
+    for (int k = 0; k < CP_KMAX; ++k) t3[k] = (valid && k < K) ? y3base[(size_t)k * fs + e] : 0.0;
+    double s = 0.0;
+#pragma unroll
+    for (int kp = 0; kp < CP_KMAX; ++kp) {
+        double a = 0.0;
+        if (kp < K) {
+#pragma unroll
+            for (int k = 0; k < CP_KMAX; ++k) a = fma(t3[k], W[k * CP_KMAX + kp], a);
+        }
+        tile[kp * CP_TS + lane] = a;
+        s += a;
+    }
+    return s;
+}
+
+// MODE 0: update (writes pout); MODE 1: monitor only (y_new := y_in, nothing written but the partials).
+// REG 0: TV (forward differences + pointwise 2x2 nuclear norm); REG 1: curvature (Laplacian + SSD).
+template <int MODE, int REG>
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *__restrict__ xc,
+                                                      const double *__restrict__ xo,
+                                                      const double *__restrict__ pin, double *__restrict__ pout,
+                                                      const double *__restrict__ g, const double *__restrict__ b,
+                                                      const double *__restrict__ W, const CpCtrl *__restrict__ ctrl,
+                                                      int cbuf_c, int cbuf_o, double *__restrict__ part) {
+    __shared__ double tiles[CP_WAVES * 16 * CP_TS];
+    __shared__ double red[CP_WAVES * CP_NSCAL];
+    if (ctrl->stop) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *tile = tiles + wave * 16 * CP_TS;
+    const int K = P.K, m = P.m, fs = P.fs;
+    const bool linear = (P.bc == 1), neumann = (P.bc == 0);
+    const double ccx = ctrl->c[cbuf_c][0], ccy = ctrl->c[cbuf_c][1];
+    const double cox = ctrl->c[cbuf_o][0], coy = ctrl->c[cbuf_o][1];
+    const double sigma = P.sigma, theta = P.theta, inv_sigma = 1.0 / P.sigma;
+    const int NY2 = (REG == 0) ? 4 : 2;
+    const double *y3in = pin + (size_t)(K + NY2 * K) * fs;
+    double *y3out = pout + (size_t)(K + NY2 * K) * fs;
+
+    double sums[CP_NSUM], maxs[CP_NMAX];
+#pragma unroll
+    for (int a = 0; a < CP_NSUM; ++a) sums[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < CP_NMAX; ++a) maxs[a] = 0.0;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+
+    for (int base = blockIdx.x * CP_BLOCK; base < P.npix; base += gridDim.x * CP_BLOCK) {
+        const int q = base + tid;
+        const bool valid = q < P.npix;
+        int i = 0, j = 0;
+        if (valid) { j = q / m; i = q - j * m; }
+        const int e = q + m;
+        const int jg = P.j_off + j;
+        const bool last_i = (i == m - 1), last_j = (jg == P.n_global - 1);
+        const bool first_i = (i == 0), first_j = (jg == 0);
+
+        load_y3_apply_W(y3in, fs, e, valid, K, W, tile, lane);
+
+        double sumLbar = 0.0;
+        for (int k = 0; k < K; ++k) {
+            if (valid) {
+                const double *uxc = xc + (size_t)(2 * k) * fs + e, *uyc = xc + (size_t)(2 * k + 1) * fs + e;
+                const double *uxo = xo + (size_t)(2 * k) * fs + e, *uyo = xo + (size_t)(2 * k + 1) * fs + e;
+                const double Lc = xc[(size_t)(2 * K + k) * fs + e], Lo = xo[(size_t)(2 * K + k) * fs + e];
+                const double Lbar = Lc + theta * (Lc - Lo);
+                // true displacement values (stored - pending mean offset) and the over-relaxed point
+                const double ux = uxc[0] - ccx, uy = uyc[0] - ccy;
+                const double uxb = ux + theta * (ux - (uxo[0] - cox)), uyb = uy + theta * (uy - (uyo[0] - coy));
+                const double gx = g[(size_t)(2 * k) * fs + e], gy = g[(size_t)(2 * k + 1) * fs + e];
+                const double bb = b[(size_t)k * fs + e];
+
+                // ---- y1: SAD* -------------------------------------------------------------------
+                const double r_cur = -(gx * ux + gy * uy) + Lc;       // (A x)_1
+                const double r_bar = -(gx * uxb + gy * uyb) + Lbar;   // (A xbar)_1
+                sums[DS_F1] += fabs(r_cur - bb);                      // NNE/SAD.m:54
+                const double y1 = pin[(size_t)k * fs + e];
+                double y1n;
+                if (MODE == 0) {
+                    const double yt = y1 + sigma * r_bar;
+                    // NNE/SAD.m:71-72 with the inner call :42-49 (sigma -> 1/sigma)
+                    const double Ls = yt * inv_sigma, thr = inv_sigma * P.mu1, dd = Ls - bb;
+                    const double prox = (dd > thr) ? (Ls - thr) : ((dd < -thr) ? (Ls + thr) : bb);
+                    y1n = yt - sigma * prox;
+                    pout[(size_t)k * fs + e] = y1n;
+                } else {
+                    y1n = y1;
+                }
+                sums[DS_F1S] += y1n * bb;                             // NNE/SAD.m:83
+                maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], fabs(y1n));
+
+                // ---- y2 -------------------------------------------------------------------------
+                if (REG == 0) {
+                    // neighbours (offset-invariant differences are still taken on true values)
+                    double uxi, uyi, uxj, uyj, uxbi, uybi, uxbj, uybj;   // "next" along i / j (or previous at a linear boundary)
+                    {
+                        const int oi = last_i ? -1 : 1;
+                        const bool need_i = !last_i || linear;
+                        const double a0 = need_i ? uxc[oi] - ccx : 0.0, a1 = need_i ? uyc[oi] - ccy : 0.0;
+                        const double o0 = need_i ? uxo[oi] - cox : 0.0, o1 = need_i ? uyo[oi] - coy : 0.0;
+                        uxi = a0; uyi = a1;
+                        uxbi = a0 + theta * (a0 - o0); uybi = a1 + theta * (a1 - o1);
+                        const int oj = last_j ? -m : m;
+                        const bool need_j = !last_j || linear;
+                        const double c0 = need_j ? uxc[oj] - ccx : 0.0, c1 = need_j ? uyc[oj] - ccy : 0.0;
+                        const double p0 = need_j ? uxo[oj] - cox : 0.0, p1 = need_j ? uyo[oj] - coy : 0.0;
+                        uxj = c0; uyj = c1;
+                        uxbj = c0 + theta * (c0 - p0); uybj = c1 + theta * (c1 - p1);
+                    }
+                    // D x (monitor) and D xbar; at a boundary row "next" holds the previous sample
+                    const double d0 = fwd_diff(ux, uxi, uxi, last_i, linear, P.inv_h1);
+                    const double d1 = fwd_diff(ux, uxj, uxj, last_j, linear, P.inv_h2);
+                    const double d2 = fwd_diff(uy, uyi, uyi, last_i, linear, P.inv_h1);
+                    const double d3 = fwd_diff(uy, uyj, uyj, last_j, linear, P.inv_h2);
+                    const double e0 = fwd_diff(uxb, uxbi, uxbi, last_i, linear, P.inv_h1);
+                    const double e1 = fwd_diff(uxb, uxbj, uxbj, last_j, linear, P.inv_h2);
+                    const double e2 = fwd_diff(uyb, uybi, uybi, last_i, linear, P.inv_h1);
+                    const double e3 = fwd_diff(uyb, uybj, uybj, last_j, linear, P.inv_h2);
+                    double s1v, s2v;
+                    sv_2x2(d0, d1, d2, d3, s1v, s2v);
+                    sums[DS_F2] += s1v + s2v;                          // NNE/pointwise_2x2_nn.m:32
+                    const double *y2 = pin + (size_t)(K + 4 * k) * fs + e;
+                    const double v0 = y2[0], v1 = y2[(size_t)fs], v2 = y2[2 * (size_t)fs], v3 = y2[3 * (size_t)fs];
+                    double n0, n1, n2, n3;
+                    if (MODE == 0) {
+                        const double t0 = v0 + sigma * e0, t1 = v1 + sigma * e1, t2 = v2 + sigma * e2,
+                                     t3 = v3 + sigma * e3;
+                        // NNE/pointwise_2x2_nn.m:46-48: M - tau * SVT_{mu/tau}(M / tau)
+                        double r0, r1, r2, r3;
+                        svt_2x2(t0 * inv_sigma, t1 * inv_sigma, t2 * inv_sigma, t3 * inv_sigma, P.mu2 * inv_sigma, r0,
+                                r1, r2, r3);
+                        n0 = t0 - sigma * r0; n1 = t1 - sigma * r1; n2 = t2 - sigma * r2; n3 = t3 - sigma * r3;
+                        double *o2 = pout + (size_t)(K + 4 * k) * fs + e;
+                        o2[0] = n0; o2[(size_t)fs] = n1; o2[2 * (size_t)fs] = n2; o2[3 * (size_t)fs] = n3;
+                    } else {
+                        n0 = v0; n1 = v1; n2 = v2; n3 = v3;
+                    }
+                    sv_2x2(n0, n1, n2, n3, s1v, s2v);
+                    maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], s1v);   // NNE/pointwise_2x2_nn.m:56
+                } else {
+                    // 5-point Laplacian, NNE/discrete_laplacian.m:23-46: a missing neighbour is the centre value
+                    // (neumann, diagonal -1/h^2) or zero (dirichlet, diagonal -2/h^2)
+                    const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
+                    double lapc[2], lapb[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const double *pc = c ? uyc : uxc, *po = c ? uyo : uxo;
+                        const double oc = c ? ccy : ccx, oo = c ? coy : cox;
+                        const double uc0 = c ? uy : ux, ub0 = c ? uyb : uxb;
+                        double nb[4], nbb[4];   // i-1, i+1, j-1, j+1
+                        const bool have[4] = {!first_i, !last_i, !first_j, !last_j};
+                        const int off[4] = {-1, 1, -m, m};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            if (have[d]) {
+                                const double a = pc[off[d]] - oc, o = po[off[d]] - oo;
+                                nb[d] = a; nbb[d] = a + theta * (a - o);
+                            } else {
+                                nb[d] = neumann ? uc0 : 0.0; nbb[d] = neumann ? ub0 : 0.0;
+                            }
+                        }
+                        lapc[c] = (nb[0] + nb[1] - 2.0 * uc0) * ih1 + (nb[2] + nb[3] - 2.0 * uc0) * ih2;
+                        lapb[c] = (nbb[0] + nbb[1] - 2.0 * ub0) * ih1 + (nbb[2] + nbb[3] - 2.0 * ub0) * ih2;
+                    }
+                    sums[DS_F2] += lapc[0] * lapc[0] + lapc[1] * lapc[1];        // NNE/SSD.m:48 (g = 0)
+                    const double *y2 = pin + (size_t)(K + 2 * k) * fs + e;
+                    const double v0 = y2[0], v1 = y2[(size_t)fs];
+                    double n0, n1;
+                    if (MODE == 0) {
+                        const double t0 = v0 + sigma * lapb[0], t1 = v1 + sigma * lapb[1];
+                        // NNE/SSD.m:60-61 with :43 (g = 0): x - tau * ((x/tau) / (1 + lambda/tau))
+                        const double den = 1.0 + P.mu2 * inv_sigma;
+                        n0 = t0 - sigma * ((t0 * inv_sigma) / den);
+                        n1 = t1 - sigma * ((t1 * inv_sigma) / den);
+                        double *o2 = pout + (size_t)(K + 2 * k) * fs + e;
+                        o2[0] = n0; o2[(size_t)fs] = n1;
+                    } else {
+                        n0 = v0; n1 = v1;
+                    }
+                    const double z0 = n0 / P.mu2, z1 = n1 / P.mu2;
+                    sums[DS_F2S] += z0 * z0 + z1 * z1;                           // NNE/SSD.m:66-67
+                }
+                sums[DS_UX] += ux;
+                sums[DS_UY] += uy;
+
+                // ---- y3 (un-projected): y3 + sigma*(Lbar - mean_k Lbar) ---------------------------
+                if (MODE == 0) tile[k * CP_TS + lane] += sigma * Lbar;
+                sumLbar += Lbar;
+            }
+        }
+        if (MODE == 0) {
+            const double sm = sigma * (sumLbar * P.invK);
+            for (int k = 0; k < K; ++k) {
+                const double v = tile[k * CP_TS + lane] - sm;
+                if (valid) {
+                    tile[k * CP_TS + lane] = v;
+                    y3out[(size_t)k * fs + e] = v;
+                }
+            }
+        }
+        __syncthreads();
+        gram_tile_accum(tile, acc);
+        __syncthreads();
+    }
+    double *out = part + (size_t)blockIdx.x * CP_PSTRIDE;
+    block_reduce_store<CP_NSUM, CP_NMAX>(sums, maxs, red, out);
+    gram_block_store(acc, tiles, out + CP_NSCAL);
+}
+
+template <int MODE, int REG>
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const double *__restrict__ xc,
+                                                        double *__restrict__ xn, const double *__restrict__ p,
+                                                        const double *__restrict__ g, const double *__restrict__ W,
+                                                        const CpCtrl *__restrict__ ctrl, int cbuf_c,
+                                                        double *__restrict__ part) {
+    __shared__ double tiles[CP_WAVES * 16 * CP_TS];
+    __shared__ double red[CP_WAVES * CP_NSCAL];
+    if (ctrl->stop) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *tile = tiles + wave * 16 * CP_TS;
+    const int K = P.K, m = P.m, fs = P.fs;
+    const bool linear = (P.bc == 1), neumann = (P.bc == 0);
+    const double ccx = ctrl->c[cbuf_c][0], ccy = ctrl->c[cbuf_c][1];
+    const double tau = P.tau;
+    const int NY2 = (REG == 0) ? 4 : 2;
+    const double *y3 = p + (size_t)(K + NY2 * K) * fs;
+
+    double sums[CP_NSUM], maxs[CP_NMAX];
+#pragma unroll
+    for (int a = 0; a < CP_NSUM; ++a) sums[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < CP_NMAX; ++a) maxs[a] = -1.0e300;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+
+    for (int base = blockIdx.x * CP_BLOCK; base < P.npix; base += gridDim.x * CP_BLOCK) {
+        const int q = base + tid;
+        const bool valid = q < P.npix;
+        int i = 0, j = 0;
+        if (valid) { j = q / m; i = q - j * m; }
+        const int e = q + m;
+        const int jg = P.j_off + j;
+
+        const double s3 = load_y3_apply_W(y3, fs, e, valid, K, W, tile, lane);
+        const double mean3 = s3 * P.invK;
+        double sumL = 0.0;
+        for (int k = 0; k < K; ++k) {
+            if (valid) {
+                const double y1 = p[(size_t)k * fs + e];
+                // (A'y)_L = y1 + B*y3     NNE/mf_nn_tv...:186-188 transposed
+                const double vL = y1 + (tile[k * CP_TS + lane] - mean3);
+                const double Lc = xc[(size_t)(2 * K + k) * fs + e];
+                double Ln;
+                if (MODE == 0) {
+                    Ln = Lc - tau * vL;                                // zero_function prox = identity
+                    xn[(size_t)(2 * K + k) * fs + e] = Ln;
+                } else {
+                    Ln = Lc;
+                }
+                tile[k * CP_TS + lane] = Ln;
+                sumL += Ln;
+                maxs[PM_VL - CP_NSUM] = fmax(maxs[PM_VL - CP_NSUM], fabs(vL));   // NNE/zero_function.m:32
+
+                const double gx = g[(size_t)(2 * k) * fs + e], gy = g[(size_t)(2 * k + 1) * fs + e];
+                double vux, vuy;
+                if (REG == 0) {
+                    const double *y2 = p + (size_t)(K + 4 * k) * fs + e;
+                    double adj[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double *f = y2 + (size_t)c * fs;
+                        const double wc = f[0];
+                        if ((c & 1) == 0) {   // Dx component: adjoint along i
+                            const double wm = (i >= 1) ? f[-1] : 0.0;
+                            const double wl = linear ? f[(m - 1) - i] : 0.0;
+                            adj[c] = fwd_diff_adj(wc, wm, wl, i, m, linear, P.inv_h1);
+                        } else {              // Dy component: adjoint along j
+                            const double wm = (jg >= 1) ? f[-m] : 0.0;
+                            const double wl = (linear && jg >= P.n_global - 2) ? f[(size_t)((P.n_global - 1) - jg) * m] : 0.0;
+                            adj[c] = fwd_diff_adj(wc, wm, wl, jg, P.n_global, linear, P.inv_h2);
+                        }
+                    }
+                    vux = -gx * y1 + (adj[0] + adj[1]);
+                    vuy = -gy * y1 + (adj[2] + adj[3]);
+                } else {
+                    const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
+                    const double *y2 = p + (size_t)(K + 2 * k) * fs + e;
+                    double lap[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const double *f = y2 + (size_t)c * fs;
+                        const double w0 = f[0];
+                        const double a0 = (i > 0) ? f[-1] : (neumann ? w0 : 0.0);
+                        const double a1 = (i < m - 1) ? f[1] : (neumann ? w0 : 0.0);
+                        const double a2 = (jg > 0) ? f[-m] : (neumann ? w0 : 0.0);
+                        const double a3 = (jg < P.n_global - 1) ? f[m] : (neumann ? w0 : 0.0);
+                        lap[c] = (a0 + a1 - 2.0 * w0) * ih1 + (a2 + a3 - 2.0 * w0) * ih2;
+                    }
+                    vux = -gx * y1 + lap[0];
+                    vuy = -gy * y1 + lap[1];
+                }
+                const double ux = xc[(size_t)(2 * k) * fs + e] - ccx, uy = xc[(size_t)(2 * k + 1) * fs + e] - ccy;
+                if (MODE == 0) {
+                    const double ntx = ux - tau * vux, nty = uy - tau * vuy;    // mean subtracted lazily (c of xn)
+                    xn[(size_t)(2 * k) * fs + e] = ntx;
+                    xn[(size_t)(2 * k + 1) * fs + e] = nty;
+                    sums[PS_UX] += ntx;
+                    sums[PS_UY] += nty;
+                }
+                // G*(-A'y): NNE/mean_zero_indicator.m:78-84 on w = -(A'y)_u
+                const double wx = -vux, wy = -vuy;
+                sums[PS_WX] += wx;
+                maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], wx);
+                maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], -wx);
+                maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], wy);
+                maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], -wy);
+            }
+        }
+        // B * L (new L in update mode, current L in monitor mode) -> Gram for the nuclear-norm feasibility
+        {
+            const double mL = sumL * P.invK;
+            for (int k = 0; k < K; ++k) {
+                const double v = valid ? tile[k * CP_TS + lane] - mL : 0.0;
+                tile[k * CP_TS + lane] = v;
+            }
+            for (int k = K; k < CP_KMAX; ++k) tile[k * CP_TS + lane] = 0.0;
+        }
+        __syncthreads();
+        gram_tile_accum(tile, acc);
+        __syncthreads();
+    }
+    double *out = part + (size_t)blockIdx.x * CP_PSTRIDE;
+    block_reduce_store<CP_NSUM, CP_NMAX>(sums, maxs, red, out);
+    gram_block_store(acc, tiles, out + CP_NSCAL);
+}

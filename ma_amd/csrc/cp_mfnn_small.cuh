@@ -1,0 +1,514 @@
+// Single-workgroup kernels of the mf_nn models: partial reduction, K x K Jacobi eigensolve,
+// l1-ball projection of the singular values, history rows and the stop rule; plus the auxiliary
+// full-grid kernels (linearisation/warp, materialise, Gram of B*field, power iteration).
+#pragma once
+#include "cp_mfnn.cuh"
+
+#define CP_HCOLS_MF 7   // [p, F1, F2, F3, G, F_con, G_con] / [q, F1*, F2*, F3*, G*, F*_con, G*_con]
+
+struct EigArgs {
+    int nblk, K, reg;
+    int rp, rd;          // primal / dual history row this kernel contributes to (-1: none)
+    int check_stop;
+    int update;          // fin: store the new mean offsets into ctrl->c[newbuf]
+    int newbuf;
+    int monitor;         // eig: the dual row describes y_in itself (row 0), not the projected y
+    double tol, mu1, mu2, sigma, Ntot;
+};
+
+// ---- reduction of the per-block partial buffer (fixed order => deterministic) -------------------
+__device__ __forceinline__ void reduce_partials(const double *__restrict__ part, int nblk, double (*G)[17],
+                                                double *sc) {
+    const int t = threadIdx.x;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int bI = 0;
+    const double *src = part + CP_NSCAL + t;
+    for (; bI + 4 <= nblk; bI += 4) {
+        a0 += src[(size_t)(bI + 0) * CP_PSTRIDE];
+        a1 += src[(size_t)(bI + 1) * CP_PSTRIDE];
+        a2 += src[(size_t)(bI + 2) * CP_PSTRIDE];
+        a3 += src[(size_t)(bI + 3) * CP_PSTRIDE];
+    }
+    for (; bI < nblk; ++bI) a0 += src[(size_t)bI * CP_PSTRIDE];
+    G[t >> 4][t & 15] = (a0 + a1) + (a2 + a3);
+    if (t < CP_NSCAL) {
+        double v = part[t];
+        for (int bb = 1; bb < nblk; ++bb) {
+            const double o = part[(size_t)bb * CP_PSTRIDE + t];
+            v = (t < CP_NSUM) ? v + o : fmax(v, o);
+        }
+        sc[t] = v;
+    }
+    __syncthreads();
+}
+
+// ---- parallel cyclic Jacobi on a symmetric 16 x 16 matrix in LDS (256 threads) -------------------
+// Round-robin ordering: 15 rounds of 8 disjoint rotations per sweep. On exit diag(G) holds the
+// eigenvalues and (WITH_V) the columns of V the eigenvectors: G_in = V diag V'.
+template <bool WITH_V>
+__device__ void jacobi16(double (*G)[17], double (*V)[17], double (*cs)[2], int (*pq)[2], int *rotflag) {
+    const int t = threadIdx.x;
+    if (WITH_V) V[t >> 4][t & 15] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
+    {   // symmetrise
+        const int r = t >> 4, c = t & 15;
+        const double s = 0.5 * (G[r][c] + G[c][r]);
+        __syncthreads();
+        G[r][c] = s;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        if (t == 0) *rotflag = 0;
+        __syncthreads();
+        for (int r = 0; r < 15; ++r) {
+            if (t < 8) {
+                int p, q;
+                if (t == 0) { p = 15; q = r; }
+                else { p = (r + t) % 15; q = (r - t + 15) % 15; }
+                if (p > q) { const int tmp = p; p = q; q = tmp; }
+                const double app = G[p][p], aqq = G[q][q], apq = G[p][q];
+                double c = 1.0, s = 0.0;
+                if (fabs(apq) > 1.0e-17 * sqrt(fabs(app * aqq)) && fabs(apq) > 1.0e-300) {
+                    const double th = (aqq - app) / (2.0 * apq);
+                    const double tt = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
+                    c = 1.0 / sqrt(tt * tt + 1.0);
+                    s = tt * c;
+                    *rotflag = 1;
+                }
+                cs[t][0] = c; cs[t][1] = s; pq[t][0] = p; pq[t][1] = q;
+            }
+            __syncthreads();
+            {   // columns: G <- G J (threads 0..127), V <- V J (threads 128..255)
+                const int pi = (t >> 4) & 7, l = t & 15;
+                const int p = pq[pi][0], q = pq[pi][1];
+                const double c = cs[pi][0], s = cs[pi][1];
+                if (t < 128) {
+                    const double gp = G[l][p], gq = G[l][q];
+                    G[l][p] = c * gp - s * gq;
+                    G[l][q] = s * gp + c * gq;
+                } else if (WITH_V) {
+                    const double vp = V[l][p], vq = V[l][q];
+                    V[l][p] = c * vp - s * vq;
+                    V[l][q] = s * vp + c * vq;
+                }
+            }
+            __syncthreads();
+            if (t < 128) {   // rows: G <- J' G
+                const int pi = t >> 4, l = t & 15;
+                const int p = pq[pi][0], q = pq[pi][1];
+                const double c = cs[pi][0], s = cs[pi][1];
+                const double gp = G[p][l], gq = G[q][l];
+                G[p][l] = c * gp - s * gq;
+                G[q][l] = s * gp + c * gq;
+            }
+            __syncthreads();
+        }
+        const int done = (*rotflag == 0);
+        __syncthreads();
+        if (done) break;
+    }
+}
+
+// ---- dual-side finalisation: W for y3, F* values, primal row rp, stop rule ------------------------
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_eig(EigArgs A, const double *__restrict__ part, CpCtrl *ctrl,
+                                                     double *__restrict__ Wout, double *hist_p, double *hist_d) {
+    __shared__ double G[16][17], V[16][17], sc[CP_NSCAL], cs[8][2], dvec[16];
+    __shared__ int pq[8][2], rotflag;
+    if (ctrl->stop) return;
+    const int t = threadIdx.x;
+    reduce_partials(part, A.nblk, G, sc);
+    jacobi16<true>(G, V, cs, pq, &rotflag);
+    if (t == 0) {
+        const int K = A.K;
+        const double nu = ctrl->nu;
+        const double mu_ = nu * A.sigma;                  // NNE/nuclear_norm_constraint.m:72
+        double S[16], z[16], zs[16];
+        double sumz = 0.0;
+        for (int i = 0; i < K; ++i) {
+            S[i] = sqrt(fmax(G[i][i], 0.0));
+            z[i] = S[i] / mu_;
+            zs[i] = z[i];
+            sumz += z[i];
+            ctrl->sv[i] = S[i];
+        }
+        double theta = 0.0;
+        const bool inside = (sumz <= 1.0);                // NNE/l1ball_projection.m:28
+        if (!inside) {
+            for (int i = 1; i < K; ++i) {                 // sort descending
+                const double v = zs[i];
+                int j = i - 1;
+                while (j >= 0 && zs[j] < v) { zs[j + 1] = zs[j]; --j; }
+                zs[j + 1] = v;
+            }
+            double cum = 0.0;
+            for (int i = 0; i < K; ++i) {
+                cum += zs[i];
+                const double th = (cum - 1.0) / (double)(i + 1);
+                if (zs[i] - th > 0.0) theta = th;         // largest such i wins (monotone)
+            }
+        }
+        double spmax = 0.0, smax = 0.0;
+        for (int i = 0; i < 16; ++i) dvec[i] = 0.0;
+        for (int i = 0; i < K; ++i) {
+            const double Pi = inside ? z[i] : fmax(z[i] - theta, 0.0);   // :65-66 (sign(z) = +)
+            const double sp = S[i] - mu_ * Pi;                           // :76
+            dvec[i] = (S[i] > 0.0) ? (mu_ * Pi) / S[i] : 0.0;
+            spmax = fmax(spmax, sp);
+            smax = fmax(smax, S[i]);
+        }
+        if (A.rd >= 0) {
+            double *hd = hist_d + (size_t)A.rd * CP_HCOLS_MF;
+            hd[1] = sc[DS_F1S];                                                    // NNE/SAD.m:83
+            hd[2] = (A.reg == 0) ? 0.0 : A.mu2 * (0.5 * sc[DS_F2S]);               // NNE/SSD.m:66-67 (g = 0)
+            // nuclear_norm_constraint.m:89: nu * max(svd(y3)); the singular values of the projected y3 are S_prox
+            hd[3] = nu * (A.monitor ? smax : spmax);
+            const double con1 = (sc[DM_Y1] > A.mu1) ? sc[DM_Y1] - A.mu1 : 0.0;     // NNE/SAD.m:77-81
+            const double con2 = (A.reg == 0) ? fmax((sc[DM_S1] - A.mu2) / A.mu2, 0.0) : 0.0;
+            hd[5] = fmax(fmax(con1, con2), 0.0);
+        }
+        if (A.rp >= 0) {
+            double *hp = hist_p + (size_t)A.rp * CP_HCOLS_MF;
+            const double F1 = A.mu1 * sc[DS_F1];
+            const double F2 = (A.reg == 0) ? A.mu2 * sc[DS_F2] : A.mu2 * 0.5 * sc[DS_F2];
+            hp[1] = F1; hp[2] = F2; hp[3] = 0.0; hp[4] = 0.0;
+            hp[0] = hp[4] + (F1 + F2 + 0.0);                                       // chambolle_pock.m:170-171
+            hp[6] = fmax(fabs(sc[DS_UX] / A.Ntot), fabs(sc[DS_UY] / A.Ntot));      // mean_zero_indicator.m:65
+            if (A.check_stop && A.rp >= 4) {                                        // chambolle_pock.m:142-153
+                bool ok = true;
+                for (int r = A.rp - 4; r <= A.rp; ++r) {
+                    const double *p_ = hist_p + (size_t)r * CP_HCOLS_MF, *d_ = hist_d + (size_t)r * CP_HCOLS_MF;
+                    const double gap = fabs((p_[0] - d_[0]) / d_[0]);
+                    if (!(gap <= A.tol) || !(p_[5] <= A.tol) || !(p_[6] <= A.tol) || !(d_[5] <= A.tol) ||
+                        !(d_[6] <= A.tol))
+                        ok = false;
+                }
+                if (ok) { ctrl->stop = 1; ctrl->stop_iter = A.rp; }
+            }
+        }
+    }
+    __syncthreads();
+    {   // W = I - V diag(d) V'
+        const int k = t >> 4, kp = t & 15;
+        double a = (k == kp) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a -= V[k][i] * dvec[i] * V[kp][i];
+        Wout[k * CP_KMAX + kp] = a;
+    }
+}
+
+// ---- primal-side finalisation: offsets c, feasibility of B*L, G* measures, dual row rd ------------
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_fin(EigArgs A, const double *__restrict__ part, CpCtrl *ctrl,
+                                                     double *hist_p, double *hist_d) {
+    __shared__ double G[16][17], sc[CP_NSCAL], cs[8][2];
+    __shared__ int pq[8][2], rotflag;
+    if (ctrl->stop) return;
+    reduce_partials(part, A.nblk, G, sc);
+    {
+        // B*L is exactly mean-free over the images, so (1,..,1) is a null vector of its Gram matrix. Rounding would
+        // turn that zero into sqrt(eps)*s_max; restrict the matrix to the orthogonal complement instead
+        // (Helmert basis q_j = (1,..,1,-j,0,..)/sqrt(j(j+1)), j = 1..K-1) before the eigensolve.
+        const int t = threadIdx.x, a = t >> 4, bq = t & 15, K = A.K;
+        double acc = 0.0;
+        if (a < K - 1 && bq < K - 1) {
+            const double na = 1.0 / sqrt((double)(a + 1) * (a + 2)), nb = 1.0 / sqrt((double)(bq + 1) * (bq + 2));
+            for (int i = 0; i <= a + 1; ++i) {
+                const double qa = (i <= a) ? na : -(double)(a + 1) * na;
+                double row = 0.0;
+                for (int j = 0; j <= bq + 1; ++j) {
+                    const double qb = (j <= bq) ? nb : -(double)(bq + 1) * nb;
+                    row += G[i][j] * qb;
+                }
+                acc += qa * row;
+            }
+        }
+        __syncthreads();
+        G[a][bq] = acc;
+        __syncthreads();
+    }
+    jacobi16<false>(G, nullptr, cs, pq, &rotflag);
+    if (threadIdx.x == 0) {
+        const double nu = ctrl->nu;
+        double sumS = 0.0;
+        for (int i = 0; i < A.K; ++i) ctrl->svL[i] = 0.0;
+        for (int i = 0; i < A.K - 1; ++i) {
+            const double s = sqrt(fmax(G[i][i], 0.0));
+            ctrl->svL[i] = s;
+            sumS += s;
+        }
+        if (A.rp >= 0)                                                             // nuclear_norm_constraint.m:55-59
+            hist_p[(size_t)A.rp * CP_HCOLS_MF + 5] = (sumS > nu) ? (sumS - nu) / nu : 0.0;
+        if (A.update) {
+            ctrl->c[A.newbuf][0] = sc[PS_UX] / A.Ntot;                             // mean_zero_indicator.m:50,53
+            ctrl->c[A.newbuf][1] = sc[PS_UY] / A.Ntot;
+        }
+        if (A.rd >= 0) {
+            double *hd = hist_d + (size_t)A.rd * CP_HCOLS_MF;
+            const double mw = sc[PS_WX] / A.Ntot;                                  // mean of u_x, used for BOTH (:78,:81)
+            const double dx = fmax(sc[PM_WXMAX] - mw, mw - (-sc[PM_WXMIN]));
+            const double dy = fmax(sc[PM_WYMAX] - mw, mw - (-sc[PM_WYMIN]));
+            hd[4] = 0.0;
+            hd[6] = fmax(fmax(dx, dy), sc[PM_VL]);                                 // mf_nn_tv...:342
+            hd[0] = -(hd[4] + (hd[1] + hd[2] + hd[3]));                            // chambolle_pock.m:175-176
+        }
+    }
+}
+
+// ---- state canonicalisation: apply pending offsets / W so that the stored vectors are the true ones ---
+template <int REG>
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_materialize(MfParams P, const double *__restrict__ xs,
+                                                             double *__restrict__ xd, const double *__restrict__ ps,
+                                                             double *__restrict__ pd, const double *__restrict__ W,
+                                                             const CpCtrl *__restrict__ ctrl, int cbuf) {
+    __shared__ double tiles[CP_WAVES * 16 * CP_TS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *tile = tiles + wave * 16 * CP_TS;
+    const int K = P.K, fs = P.fs;
+    const double cx = ctrl->c[cbuf][0], cy = ctrl->c[cbuf][1];
+    const int NY2 = (REG == 0) ? 4 : 2;
+    for (int base = blockIdx.x * CP_BLOCK; base < P.npix; base += gridDim.x * CP_BLOCK) {
+        const int q = base + tid;
+        const bool valid = q < P.npix;
+        const int e = q + P.m;
+        load_y3_apply_W(ps + (size_t)(K + NY2 * K) * fs, fs, e, valid, K, W, tile, lane);
+        if (valid) {
+            for (int k = 0; k < K; ++k) {
+                xd[(size_t)(2 * k) * fs + e] = xs[(size_t)(2 * k) * fs + e] - cx;
+                xd[(size_t)(2 * k + 1) * fs + e] = xs[(size_t)(2 * k + 1) * fs + e] - cy;
+                xd[(size_t)(2 * K + k) * fs + e] = xs[(size_t)(2 * K + k) * fs + e];
+                pd[(size_t)(K + NY2 * K + k) * fs + e] = tile[k * CP_TS + lane];
+            }
+            if (ps != pd)
+                for (int f = 0; f < K + NY2 * K; ++f) pd[(size_t)f * fs + e] = ps[(size_t)f * fs + e];
+        }
+    }
+}
+
+__global__ void k_mf_reset_ctrl(CpCtrl *ctrl, double *W0, double *W1) {
+    const int t = threadIdx.x;
+    if (t == 0) {
+        ctrl->stop = 0; ctrl->stop_iter = -1;
+        ctrl->c[0][0] = ctrl->c[0][1] = ctrl->c[1][0] = ctrl->c[1][1] = 0.0;
+    }
+    const double v = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
+    W0[t] = v;
+    W1[t] = v;
+}
+
+// ---- linearisation: T(u0), grad T(u0), b = T(u0) - grad T . u0   --------------------------------------
+// IRE/evaluate_displacement.m:38-49 -> IRE/cell_centered_grid.m:20-29 -> IRE/bilinear_interpolation.m:29-105.
+// Coordinate arithmetic uses explicitly rounded (non-fused) operations so that floor() -- the index
+// logic -- is bit-identical to the CPU restatement.
+struct WarpParams {
+    int m, nl, K, npix, n_global, j_off, fs;
+    int mi, ni;              // image size (rows, cols) -- equals (m, n_global) in the drivers
+    int ifs;                 // image field stride (mi*ni)
+    double om0, om2, hx, hy; // grid origin and cell size
+    double inv_h1, inv_h2;   // 1/h of the image (h passed to evaluate_displacement)
+};
+
+// one thread per (pixel, image); u is read from x fields [2k], [2k+1] (true values: canonical state)
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_warp(WarpParams P, const double *__restrict__ imgs,
+                                                      const double *__restrict__ x, double *__restrict__ Tu,
+                                                      double *__restrict__ g, double *__restrict__ b) {
+    const long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x;
+    if (gid >= (long long)P.npix * P.K) return;
+    const int k = (int)(gid / P.npix), q = (int)(gid - (long long)k * P.npix);
+    const int j = q / P.m, i = q - j * P.m, e = q + P.m;
+    const double ux = x[(size_t)(2 * k) * P.fs + e], uy = x[(size_t)(2 * k + 1) * P.fs + e];
+    const double px = __dadd_rn(__dadd_rn(P.om0, __dmul_rn(P.hx, (double)i + 0.5)), ux);
+    const double py = __dadd_rn(__dadd_rn(P.om2, __dmul_rn(P.hy, (double)(P.j_off + j) + 0.5)), uy);
+    double val, dx, dy;
+    bilinear_tap(imgs + (size_t)k * P.ifs, P.mi, P.ni, px, py, P.inv_h1, P.inv_h2, val, dx, dy);
+    Tu[(size_t)k * P.fs + e] = val;
+    g[(size_t)(2 * k) * P.fs + e] = dx;
+    g[(size_t)(2 * k + 1) * P.fs + e] = dy;
+    b[(size_t)k * P.fs + e] = val - (dx * ux + dy * uy);               // NNE/mf_nn_tv...:167-168
+}
+
+// ---- Gram of (B*field)*Vm for accurate singular values (nu_0, SV_history) -----------------------------
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_gram_field(MfParams P, const double *__restrict__ field,
+                                                            const double *__restrict__ Vm,
+                                                            double *__restrict__ part) {
+    __shared__ double tiles[CP_WAVES * 16 * CP_TS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *tile = tiles + wave * 16 * CP_TS;
+    const int K = P.K, fs = P.fs;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int base = blockIdx.x * CP_BLOCK; base < P.npix; base += gridDim.x * CP_BLOCK) {
+        const int q = base + tid;
+        const bool valid = q < P.npix;
+        const int e = q + P.m;
+        double t3[CP_KMAX];
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < CP_KMAX; ++k) {
+            t3[k] = (valid && k < K) ? field[(size_t)k * fs + e] : 0.0;
+            s += t3[k];
+        }
+        const double mean = s * P.invK;
+#pragma unroll
+        for (int k = 0; k < CP_KMAX; ++k) t3[k] = (valid && k < K) ? t3[k] - mean : 0.0;   // mean_free_operator.m:20
+#pragma unroll
+        for (int kp = 0; kp < CP_KMAX; ++kp) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < CP_KMAX; ++k) a = fma(t3[k], Vm[k * CP_KMAX + kp], a);
+            tile[kp * CP_TS + lane] = a;
+        }
+        __syncthreads();
+        gram_tile_accum(tile, acc);
+        __syncthreads();
+    }
+    gram_block_store(acc, tiles, part + (size_t)blockIdx.x * CP_PSTRIDE + CP_NSCAL);
+}
+
+// reduce + Jacobi; out[0..15] eigenvalues (diag), out[16..271] eigenvector matrix composed with Vin
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_sv_eig(int nblk, const double *__restrict__ part,
+                                                        const double *__restrict__ Vin, double *__restrict__ out) {
+    __shared__ double G[16][17], V[16][17], sc[CP_NSCAL], cs[8][2];
+    __shared__ int pq[8][2], rotflag;
+    const int t = threadIdx.x;
+    {   // only the Gram part of the partials is valid here
+        double a0 = 0.0;
+        for (int bI = 0; bI < nblk; ++bI) a0 += part[(size_t)bI * CP_PSTRIDE + CP_NSCAL + t];
+        G[t >> 4][t & 15] = a0;
+        if (t < CP_NSCAL) sc[t] = 0.0;
+        __syncthreads();
+    }
+    jacobi16<true>(G, V, cs, pq, &rotflag);
+    if (t < 16) out[t] = G[t][t];
+    {   // Vout = Vin * V
+        const int k = t >> 4, kp = t & 15;
+        double a = 0.0;
+        for (int i = 0; i < 16; ++i) a += Vin[k * CP_KMAX + i] * V[i][kp];
+        out[16 + t] = a;
+    }
+}
+
+// ---- power iteration of NNE/matrix_norm.m on A = [-grad T, I; D|Lap, 0; 0, B] -------------------------------
+// y = A*(scale*x)
+template <int REG>
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_applyA(MfParams P, const double *__restrict__ x, double scale,
+                                                        const double *__restrict__ g, double *__restrict__ y) {
+    const int K = P.K, m = P.m, fs = P.fs;
+    const bool linear = (P.bc == 1), neumann = (P.bc == 0);
+    const int NY2 = (REG == 0) ? 4 : 2;
+    for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
+        const int j = q / m, i = q - j * m, e = q + m, jg = P.j_off + j;
+        const bool last_i = (i == m - 1), last_j = (jg == P.n_global - 1), first_i = (i == 0), first_j = (jg == 0);
+        double sumL = 0.0;
+        for (int k = 0; k < K; ++k) sumL += scale * x[(size_t)(2 * K + k) * fs + e];
+        const double mean = sumL * P.invK;
+        for (int k = 0; k < K; ++k) {
+            const double *ux = x + (size_t)(2 * k) * fs + e, *uy = x + (size_t)(2 * k + 1) * fs + e;
+            const double L = scale * x[(size_t)(2 * K + k) * fs + e];
+            const double u0 = scale * ux[0], v0 = scale * uy[0];
+            y[(size_t)k * fs + e] = -(g[(size_t)(2 * k) * fs + e] * u0 + g[(size_t)(2 * k + 1) * fs + e] * v0) + L;
+            y[(size_t)(K + NY2 * K + k) * fs + e] = L - mean;
+            if (REG == 0) {
+                const int oi = last_i ? -1 : 1, oj = last_j ? -m : m;
+                const bool ni_ = !last_i || linear, nj_ = !last_j || linear;
+                const double uxi = ni_ ? scale * ux[oi] : 0.0, uyi = ni_ ? scale * uy[oi] : 0.0;
+                const double uxj = nj_ ? scale * ux[oj] : 0.0, uyj = nj_ ? scale * uy[oj] : 0.0;
+                double *o = y + (size_t)(K + 4 * k) * fs + e;
+                o[0] = fwd_diff(u0, uxi, uxi, last_i, linear, P.inv_h1);
+                o[(size_t)fs] = fwd_diff(u0, uxj, uxj, last_j, linear, P.inv_h2);
+                o[2 * (size_t)fs] = fwd_diff(v0, uyi, uyi, last_i, linear, P.inv_h1);
+                o[3 * (size_t)fs] = fwd_diff(v0, uyj, uyj, last_j, linear, P.inv_h2);
+            } else {
+                const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const double *f = c ? uy : ux;
+                    const double w0 = scale * f[0];
+                    const double a0 = !first_i ? scale * f[-1] : (neumann ? w0 : 0.0);
+                    const double a1 = !last_i ? scale * f[1] : (neumann ? w0 : 0.0);
+                    const double a2 = !first_j ? scale * f[-m] : (neumann ? w0 : 0.0);
+                    const double a3 = !last_j ? scale * f[m] : (neumann ? w0 : 0.0);
+                    y[(size_t)(K + 2 * k + c) * fs + e] = (a0 + a1 - 2.0 * w0) * ih1 + (a2 + a3 - 2.0 * w0) * ih2;
+                }
+            }
+        }
+    }
+}
+
+// xo = A'*y and per-block partial sums of ||xo||^2 (part[blk*CP_PSTRIDE + 0])
+template <int REG>
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_applyAT(MfParams P, const double *__restrict__ y,
+                                                         const double *__restrict__ g, double *__restrict__ xo,
+                                                         double *__restrict__ part) {
+    __shared__ double red[CP_WAVES * 2];
+    const int K = P.K, m = P.m, fs = P.fs;
+    const bool linear = (P.bc == 1), neumann = (P.bc == 0);
+    const int NY2 = (REG == 0) ? 4 : 2;
+    double ss[1] = {0.0}, mm[1] = {0.0};
+    for (int base = blockIdx.x * CP_BLOCK; base < P.npix; base += gridDim.x * CP_BLOCK) {
+        const int q = base + threadIdx.x;
+        if (q < P.npix) {
+            const int j = q / m, i = q - j * m, e = q + m, jg = P.j_off + j;
+            double s3 = 0.0;
+            for (int k = 0; k < K; ++k) s3 += y[(size_t)(K + NY2 * K + k) * fs + e];
+            const double mean3 = s3 * P.invK;
+            for (int k = 0; k < K; ++k) {
+                const double y1 = y[(size_t)k * fs + e];
+                const double vL = y1 + (y[(size_t)(K + NY2 * K + k) * fs + e] - mean3);
+                xo[(size_t)(2 * K + k) * fs + e] = vL;
+                const double gx = g[(size_t)(2 * k) * fs + e], gy = g[(size_t)(2 * k + 1) * fs + e];
+                double vux, vuy;
+                if (REG == 0) {
+                    const double *y2 = y + (size_t)(K + 4 * k) * fs + e;
+                    double adj[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double *f = y2 + (size_t)c * fs;
+                        const double wc = f[0];
+                        if ((c & 1) == 0) {
+                            const double wm = (i >= 1) ? f[-1] : 0.0;
+                            const double wl = linear ? f[(m - 1) - i] : 0.0;
+                            adj[c] = fwd_diff_adj(wc, wm, wl, i, m, linear, P.inv_h1);
+                        } else {
+                            const double wm = (jg >= 1) ? f[-m] : 0.0;
+                            const double wl = (linear && jg >= P.n_global - 2) ? f[(size_t)((P.n_global - 1) - jg) * m] : 0.0;
+                            adj[c] = fwd_diff_adj(wc, wm, wl, jg, P.n_global, linear, P.inv_h2);
+                        }
+                    }
+                    vux = -gx * y1 + (adj[0] + adj[1]);
+                    vuy = -gy * y1 + (adj[2] + adj[3]);
+                } else {
+                    const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
+                    const double *y2 = y + (size_t)(K + 2 * k) * fs + e;
+                    double lap[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const double *f = y2 + (size_t)c * fs;
+                        const double w0 = f[0];
+                        const double a0 = (i > 0) ? f[-1] : (neumann ? w0 : 0.0);
+                        const double a1 = (i < m - 1) ? f[1] : (neumann ? w0 : 0.0);
+                        const double a2 = (jg > 0) ? f[-m] : (neumann ? w0 : 0.0);
+                        const double a3 = (jg < P.n_global - 1) ? f[m] : (neumann ? w0 : 0.0);
+                        lap[c] = (a0 + a1 - 2.0 * w0) * ih1 + (a2 + a3 - 2.0 * w0) * ih2;
+                    }
+                    vux = -gx * y1 + lap[0];
+                    vuy = -gy * y1 + lap[1];
+                }
+                xo[(size_t)(2 * k) * fs + e] = vux;
+                xo[(size_t)(2 * k + 1) * fs + e] = vuy;
+                ss[0] += vux * vux + vuy * vuy + vL * vL;
+            }
+        }
+    }
+    block_reduce_store<1, 1>(ss, mm, red, part + (size_t)blockIdx.x * CP_PSTRIDE);
+}
+
+// deterministic start vector of the power iteration (global MATLAB index -> hash)
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_hash_start(MfParams P, double *__restrict__ x) {
+    const long long tot = (long long)P.npix * 3 * P.K;
+    for (long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot;
+         gid += (long long)gridDim.x * CP_BLOCK) {
+        const int f = (int)(gid / P.npix), q = (int)(gid - (long long)f * P.npix);
+        const int j = q / P.m, i = q - j * P.m;
+        const unsigned long long idx =
+            (unsigned long long)f * ((unsigned long long)P.m * P.n_global) + (unsigned long long)(P.j_off + j) * P.m + i;
+        const unsigned long long hsh = (idx * 2654435761ULL) & 0xFFFFFFFFULL;
+        x[(size_t)f * P.fs + q + P.m] = (double)hsh / 2147483648.0 - 1.0;
+    }
+}

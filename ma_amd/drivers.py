@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference's entry points for the primal-dual hot path.
+
+Same names, argument meaning and return values as the MATLAB sources; the arithmetic runs in
+libcpengine.so (HIP, device resident).  F, G, K are operator structs (type tag + parameters)
+returned by same-named constructors and recognised by `chambolle_pock` -- arbitrary closures and
+sparse matrices cannot be fused, see INTEGRATION.md.
+"""
+from dataclasses import dataclass
+import math
+
+import numpy as np
+
+from . import engine as E
+
+
+def normalize(x):
+    """(x - min) / (max - min), NNE/mf_nn_tv_registration_no_ref_ml.m:43"""
+    x = np.asarray(x, dtype=np.float64)
+    return (x - x.min()) / (x.max() - x.min())
+
+
+def _vecF(a):
+    return np.asarray(a, dtype=np.float64).reshape(-1, order="F")
+
+
+# ------------------------------------------------------------------------------------------------
+# operator structs (reference: closures  F = @(v, c_flag) TV_registration(v, sigma, c_flag)  etc.)
+@dataclass
+class TV_registration:      # PDO/TV_registration.m
+    sigma: float
+
+
+@dataclass
+class TV_denoise:           # PDO/TV_denoise.m
+    sigma: float
+
+
+@dataclass
+class SAD_registration:     # PDO/SAD_registration.m  (u, u0, T, R, h, lambda, tau, flag)
+    u0: np.ndarray
+    T: np.ndarray
+    R: np.ndarray
+    h: tuple
+    lam: float
+    tau: float
+
+
+@dataclass
+class SSD_registration:     # PDO/SSD_registration.m
+    u0: np.ndarray
+    T: np.ndarray
+    R: np.ndarray
+    h: tuple
+    lam: float
+    tau: float
+
+
+@dataclass
+class SAD_denoise:          # PDO/SAD_denoise.m (u, g, lambda, tau, flag)
+    g: np.ndarray
+    lam: float
+    tau: float
+
+
+@dataclass
+class GradientOperator:
+    """K = kron(I_ncomp, [Gx; Gy]) with Neumann rows, PDO/test_TV_L1_registration.m:67-72"""
+    m: int
+    n: int
+    h: tuple
+    ncomp: int
+
+    def norm_bound_squared(self):
+        # ||K||_1 * ||K||_inf as in PDO/chambolle_pock.m:58-59
+        col = 2.0 / self.h[0] + 2.0 / self.h[1]
+        row = max(2.0 / self.h[0], 2.0 / self.h[1])
+        return col * row
+
+
+def chambolle_pock(F, G, K, x0, y0, theta=None, tau=None, sigma=None, maxIter=None, tol=None, device=0):
+    """[x_star, y_star, primal_history, dual_history] = chambolle_pock(F, G, K, x0, y0, theta, tau, sigma,
+    maxIter, tol) with the nargin defaults of PDO/chambolle_pock.m:54-70."""
+    if tol is None:
+        tol = 1e-3
+    if maxIter is None:
+        maxIter = 300
+    if not isinstance(K, GradientOperator):
+        raise TypeError("cpengine: K must be an operator struct recognised by the engine")
+    if sigma is None and tau is not None:
+        sigma = 1.0 / (K.norm_bound_squared() * tau)
+    if tau is None:
+        tau = 1.0 / math.sqrt(K.norm_bound_squared())
+        sigma = tau
+    if theta is None:
+        theta = 1.0
+    m, n = K.m, K.n
+    if isinstance(F, TV_registration) and isinstance(G, (SAD_registration, SSD_registration)) and K.ncomp == 2:
+        model = E.MODEL_TV_L1_REG if isinstance(G, SAD_registration) else E.MODEL_TV_L2_REG
+        eng = E.Engine(model, m, n, h=K.h, lam=G.lam, device=device)
+        eng.set_images(_vecF(G.T), _vecF(G.R))
+        eng.linearize(np.asarray(G.u0, dtype=np.float64))
+    elif isinstance(F, TV_denoise) and isinstance(G, SAD_denoise) and K.ncomp == 1:
+        eng = E.Engine(E.MODEL_TV_L1_DENOISE, m, n, h=K.h, lam=G.lam, device=device)
+        eng.set_images(_vecF(G.g))
+    else:
+        raise TypeError("cpengine: unsupported (F, G, K) combination")
+    try:
+        eng.set_primal(x0)
+        eng.set_dual(y0)
+        eng.solve(theta, tau, sigma, maxIter, tol)
+        ph, dh = eng.history()
+        return eng.primal(), eng.dual(), ph, dh
+    finally:
+        eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+def tv_registration(R, T, lam, tau, maxIter, numSteps, data_term="SAD", h=(1.0, 1.0), theta=1.0, device=0,
+                    keep_histories=False):
+    """The script PDO/test_TV_L1_registration.m:56-122 (data_term='SAD') / PDO/test_TV_L2_registration.m
+    ('SSD') as a function: outer re-linearisation loop with warm start, state resident on the device."""
+    R = normalize(R)
+    T = normalize(T)
+    m, n = R.shape
+    L_squared = 4 * (1 / h[0] ** 2 + 1 / h[1] ** 2)
+    sigma = (1 - 1e-4) / (L_squared * tau)
+    model = E.MODEL_TV_L1_REG if data_term == "SAD" else E.MODEL_TV_L2_REG
+    eng = E.Engine(model, m, n, h=h, lam=lam, device=device)
+    hist = []
+    try:
+        eng.set_images(_vecF(T), _vecF(R))
+        for _ in range(numSteps):
+            eng.linearize()                                   # u0 <- u_star (:119-120)
+            eng.solve(theta, tau, sigma, maxIter, 1e-3)        # tol default (:116-117)
+            if keep_histories:
+                hist.append(eng.history())
+        return eng.primal(), eng.dual(), hist, dict(sigma=sigma)
+    finally:
+        eng.close()
+
+
+def tv_l1_denoising(img_noisy, lam=1.5, tau=0.02, maxIter=1000, tol=1e-5, h=(1.0, 1.0), theta=1.0, device=0):
+    """PDO/test_TV_L1_denoising.m:29-63"""
+    img_noisy = np.asarray(img_noisy, dtype=np.float64)
+    m, n = img_noisy.shape
+    L_squared = 4 * (1 / h[0] ** 2 + 1 / h[1] ** 2)
+    sigma = (1 - 1e-4) / (L_squared * tau)
+    eng = E.Engine(E.MODEL_TV_L1_DENOISE, m, n, h=h, lam=lam, device=device)
+    try:
+        eng.set_images(_vecF(img_noisy))
+        eng.solve(theta, tau, sigma, maxIter, tol)
+        ph, dh = eng.history()
+        return eng.primal(), eng.dual(), ph, dh, sigma
+    finally:
+        eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+def num_levels(m, n):
+    return int(min(math.floor(math.log2(m) - 5), math.floor(math.log2(n) - 5))) + 1   # mf_nn_tv...:59
+
+
+def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True):
+    k = len(img)
+    img = [normalize(im) for im in img]
+    m, n = img[0].shape
+    omega = [0.0, float(m), 0.0, float(n)]
+    levels = num_levels(m, n)
+    max_outer = int(max(optPara["outerIter"]))
+    u = [[None] * max_outer for _ in range(levels)]
+    L = [[None] * max_outer for _ in range(levels)]
+    SV_history = [None] * levels
+    model = E.MODEL_MF_NN_TV if reg == "tv" else E.MODEL_MF_NN_CURV
+    # level sizes (finest last), NNE/mf_nn_tv...:67-79
+    sizes = [(m, n)]
+    for _ in range(levels - 1):
+        sizes.insert(0, ((sizes[0][0] + 1) // 2, (sizes[0][1] + 1) // 2))
+    engines = []
+    try:
+        for (ml, nl) in sizes:
+            h_grid = ((omega[1] - omega[0]) / ml, (omega[3] - omega[2]) / nl)          # (:88)
+            engines.append(E.Engine(model, ml, nl, k=k, bc=optPara["bc"], h=h_grid, omega=omega, mu=optPara["mu"],
+                                    device=device))
+        engines[-1].set_images(np.concatenate([_vecF(im) for im in img]))
+        for lev in range(levels - 1, 0, -1):
+            engines[lev].downsample_to(engines[lev - 1])
+        nu = None
+        for lev in range(levels):
+            eng = engines[lev]
+            ml, nl = sizes[lev]
+            sel = 0 if lev == 0 else 1
+            outerIter = int(optPara["outerIter"][sel])
+            nu_factor = optPara["nu_factor"][sel]
+            if lev > 0:
+                eng.prolong_from(engines[lev - 1], 1.0)                                # (:111-119), p = 0 (:122)
+                engines[lev - 1].close()
+            SV_history[lev] = np.zeros((k, max_outer))
+            for o in range(outerIter):
+                eng.linearize()                                                        # (:164-169)
+                if o == 0 and lev == 0:
+                    nu = nu_factor * float(np.sum(eng.singular_values(0)))             # (:173-175)
+                elif o == 0:
+                    nu = 2 * nu_factor * nu                                            # (:177)
+                else:
+                    nu = nu_factor * nu                                                # (:179)
+                eng.set_nu(nu)
+                x0n = normest_x0(3 * k * ml * nl) if normest_x0 is not None else None
+                norm_A_est, n_power = eng.norm_estimate(x0n)                           # (:191-192)
+                tau = math.sqrt(0.99 / norm_A_est ** 2)
+                sigma = math.sqrt(0.99 / norm_A_est ** 2)
+                res = eng.solve(optPara["theta"], tau, sigma, optPara["maxIter"], optPara["tol"])
+                last = (lev == levels - 1) and (o == outerIter - 1)
+                if download_all or last:
+                    x = eng.primal()
+                    kmn = k * ml * nl
+                    u[lev][o] = x[: 2 * kmn].reshape((ml * nl, 2, k), order="F")
+                    L[lev][o] = x[2 * kmn:].reshape((ml, nl, k), order="F")
+                SV_history[lev][:, o] = eng.singular_values(1)                         # (:214-215)
+                if keep is not None:
+                    ph, dh = eng.history()
+                    keep[(lev, o)] = dict(nu=nu, tau=tau, sigma=sigma, norm_est=norm_A_est, n_power=n_power,
+                                          primal_history=ph, dual_history=dh, iterations=res.iterations,
+                                          stop_reason=res.stop_reason)
+        return u, L, SV_history
+    finally:
+        for e in engines:
+            e.close()
+
+
+def mf_nn_tv_registration_no_ref_ml(img, optPara, **kw):
+    """[u, L, SV_history] = mf_nn_tv_registration_no_ref_ml(img, optPara)   (NNE/mf_nn_tv_registration_no_ref_ml.m:8)"""
+    return _mf_nn_ml(img, optPara, "tv", **kw)
+
+
+def mf_nn_curvature_registration_no_ref_ml(img, optPara, **kw):
+    """[u0, L0, SV_history] = mf_nn_curvature_registration_no_ref_ml(img, optPara): the reference returns only the
+    last iterate (NNE/mf_nn_curvature_registration_no_ref_ml.m:8,204-206)."""
+    u, L, SV = _mf_nn_ml(img, optPara, "curvature", **kw)
+    lev = len(u) - 1
+    o = int(optPara["outerIter"][0 if lev == 0 else 1]) - 1
+    return u[lev][o], L[lev][o].reshape(-1, order="F"), SV

@@ -1,0 +1,240 @@
+"""ctypes binding of libcpengine.so (include/cpengine.h).
+
+The library is the product; there is no CPU fallback.  If the shared object is missing the
+import of this module fails loudly (build it with `python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpengine.so")
+
+MODEL_TV_L1_DENOISE, MODEL_TV_L1_REG, MODEL_TV_L2_REG, MODEL_MF_NN_TV, MODEL_MF_NN_CURV = 1, 2, 3, 4, 5
+BC = {"neumann": 0, "linear": 1, "dirichlet": 2}
+STOP_MAXITER, STOP_TOLERANCE = 0, 1
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+        ("bc", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("reserved0", C.c_int32),
+        ("h", C.c_double * 2), ("omega", C.c_double * 4),
+        ("lambda_", C.c_double), ("mu", C.c_double),
+        ("n_global", C.c_int32), ("j_offset", C.c_int32),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("stop_reason", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
+class CpEngineError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP engine is not built. Run __graft_entry__.build() "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    vp = C.c_void_p
+    lib.cp_last_error.restype = C.c_char_p
+    lib.cp_version.restype = C.c_char_p
+    sigs = {
+        "cp_create": [C.POINTER(ProblemDesc), C.POINTER(vp)],
+        "cp_destroy": [vp],
+        "cp_set_images": [vp, dp, dp],
+        "cp_set_primal": [vp, dp],
+        "cp_set_dual": [vp, dp],
+        "cp_linearize": [vp, dp],
+        "cp_get_linearization": [vp, dp, dp, dp],
+        "cp_set_nu": [vp, C.c_double],
+        "cp_singular_values": [vp, C.c_int, dp],
+        "cp_norm_estimate": [vp, dp, dp, C.POINTER(C.c_int32)],
+        "cp_solve": [vp, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_double, C.POINTER(Result)],
+        "cp_get_result": [vp, C.c_int32, C.POINTER(Result)],
+        "cp_get_history": [vp, dp, dp],
+        "cp_get_primal": [vp, dp],
+        "cp_get_dual": [vp, dp],
+        "cp_get_images": [vp, dp],
+        "cp_prolong": [vp, vp, C.c_double],
+        "cp_downsample": [vp, vp],
+        "cp_iterate": [vp, C.c_double, C.c_double, C.c_double, C.c_int32],
+        "cp_sync": [vp],
+        "cp_kernel_time_ms": [vp, C.c_char_p, dp, C.POINTER(C.c_int64)],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    return lib
+
+
+lib = _load()
+EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_images", "cp_set_primal", "cp_set_dual",
+            "cp_linearize", "cp_get_linearization", "cp_set_nu", "cp_singular_values", "cp_norm_estimate", "cp_solve",
+            "cp_get_result", "cp_get_history", "cp_get_primal", "cp_get_dual", "cp_get_images", "cp_prolong",
+            "cp_downsample", "cp_iterate", "cp_sync", "cp_kernel_time_ms"]
+
+
+def _chk(rc):
+    if rc != 0:
+        raise CpEngineError(lib.cp_last_error().decode())
+
+
+def _dptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a):
+    """host vector in MATLAB (column-major) order as a contiguous float64 array"""
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+
+
+class Engine:
+    """One handle = one (F, G, K) triple of the reference at one resolution."""
+
+    def __init__(self, model, m, n, k=1, bc="neumann", h=(1.0, 1.0), omega=None, lam=0.0, mu=0.0, device=0,
+                 batch=1, n_global=0, j_offset=0):
+        d = ProblemDesc()
+        d.model, d.m, d.n, d.k = model, m, n, k
+        if bc not in BC:
+            raise CpEngineError("cpengine:badBC Unknown boundary condition!")
+        d.bc, d.device, d.batch = BC[bc], device, batch
+        d.h[0], d.h[1] = float(h[0]), float(h[1])
+        if omega is not None:
+            for i in range(4):
+                d.omega[i] = float(omega[i])
+        d.lambda_, d.mu = float(lam), float(mu)
+        d.n_global, d.j_offset = n_global, j_offset
+        self.desc = d
+        self.model, self.m, self.n, self.k, self.batch = model, m, n, k, batch
+        self.mf = model in (MODEL_MF_NN_TV, MODEL_MF_NN_CURV)
+        if self.mf:
+            self.nx = 3 * k * m * n
+            self.ny = (6 if model == MODEL_MF_NN_TV else 4) * k * m * n
+            self.cols = 7
+        else:
+            nc = 1 if model == MODEL_TV_L1_DENOISE else 2
+            self.nx = nc * m * n * batch
+            self.ny = 2 * nc * m * n * batch
+            self.cols = 5
+        self._h = C.c_void_p()
+        _chk(lib.cp_create(C.byref(d), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib.cp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # data in
+    def set_images(self, a, b=None):
+        a, b = _f64(a), _f64(b)
+        _chk(lib.cp_set_images(self._h, _dptr(a), _dptr(b)))
+
+    def set_primal(self, x0=None):
+        x0 = _f64(x0)
+        _chk(lib.cp_set_primal(self._h, _dptr(x0)))
+
+    def set_dual(self, y0=None):
+        y0 = _f64(y0)
+        _chk(lib.cp_set_dual(self._h, _dptr(y0)))
+
+    def linearize(self, u0=None):
+        u0 = _f64(u0)
+        _chk(lib.cp_linearize(self._h, _dptr(u0)))
+
+    def get_linearization(self):
+        kk = self.k * self.batch
+        T = np.empty(kk * self.m * self.n)
+        g = np.empty(2 * kk * self.m * self.n)
+        b = np.empty(kk * self.m * self.n)
+        _chk(lib.cp_get_linearization(self._h, _dptr(T), _dptr(g), _dptr(b)))
+        return T, g, b
+
+    def set_nu(self, nu):
+        _chk(lib.cp_set_nu(self._h, float(nu)))
+
+    def singular_values(self, which):
+        sv = np.empty(self.k)
+        _chk(lib.cp_singular_values(self._h, int(which), _dptr(sv)))
+        return sv
+
+    def norm_estimate(self, x0=None):
+        x0 = _f64(x0)
+        est = C.c_double()
+        it = C.c_int32()
+        _chk(lib.cp_norm_estimate(self._h, _dptr(x0), C.byref(est), C.byref(it)))
+        return est.value, it.value
+
+    def solve(self, theta, tau, sigma, max_iter, tol):
+        r = Result()
+        _chk(lib.cp_solve(self._h, theta, tau, sigma, int(max_iter), tol, C.byref(r)))
+        return r
+
+    def result(self, problem=0):
+        r = Result()
+        _chk(lib.cp_get_result(self._h, problem, C.byref(r)))
+        return r
+
+    def history(self):
+        """(primal_history, dual_history); for a batch: lists with one pair of arrays per problem"""
+        res = [self.result(p) for p in range(self.batch)]
+        tot = sum(r.rows * r.cols for r in res)
+        ph = np.empty(tot)
+        dh = np.empty(tot)
+        _chk(lib.cp_get_history(self._h, _dptr(ph), _dptr(dh)))
+        outp, outd, off = [], [], 0
+        for r in res:
+            sz = r.rows * r.cols
+            outp.append(ph[off:off + sz].reshape((r.rows, r.cols), order="F").copy())
+            outd.append(dh[off:off + sz].reshape((r.rows, r.cols), order="F").copy())
+            off += sz
+        if self.batch == 1:
+            return outp[0], outd[0]
+        return outp, outd
+
+    def primal(self):
+        x = np.empty(self.nx)
+        _chk(lib.cp_get_primal(self._h, _dptr(x)))
+        return x
+
+    def dual(self):
+        y = np.empty(self.ny)
+        _chk(lib.cp_get_dual(self._h, _dptr(y)))
+        return y
+
+    def images(self):
+        n_g = self.desc.n_global if self.desc.n_global > 0 else self.n
+        a = np.empty(self.k * self.m * n_g * self.batch)
+        _chk(lib.cp_get_images(self._h, _dptr(a)))
+        return a
+
+    def prolong_from(self, coarse, factor=1.0):
+        _chk(lib.cp_prolong(coarse._h, self._h, float(factor)))
+
+    def downsample_to(self, coarse):
+        _chk(lib.cp_downsample(self._h, coarse._h))
+
+    # benchmarking hooks
+    def iterate(self, theta, tau, sigma, iters):
+        _chk(lib.cp_iterate(self._h, theta, tau, sigma, int(iters)))
+
+    def sync(self):
+        _chk(lib.cp_sync(self._h))
+
+    def kernel_time_ms(self, name):
+        ms = C.c_double()
+        n = C.c_int64()
+        _chk(lib.cp_kernel_time_ms(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

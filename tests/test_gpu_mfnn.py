@@ -1,0 +1,72 @@
+"""GPU parity of the mf_nn (NN-TV / NN-curvature) hot path: HIP engine through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10   # north_star: fp64 within 1e-10 relative on the displacement field and final energy
+
+
+def _setup(m, n, k, reg, bc, amp=1.5):
+    from ma_amd import synth
+    from oracle import drivers as od
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    u0 = synth.smooth_displacement(m, n, k, amp=amp).numpy().reshape(k, 2, n * m)
+    u0_ref = np.transpose(u0, (2, 1, 0))
+    omega = [0.0, float(m), 0.0, float(n)]
+    h = (1.0, 1.0)
+    A, b, T_u, gs = od.mf_nn_problem([imgs[i] for i in range(k)], u0_ref, h, omega, reg, bc)
+    return imgs, u0, omega, h, A, b, T_u, gs
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("reg,bc,m,n,k", [("tv", "neumann", 48, 40, 3), ("tv", "linear", 33, 50, 4),
+                                          ("curvature", "dirichlet", 40, 36, 3), ("curvature", "neumann", 70, 55, 5),
+                                          ("tv", "neumann", 64, 64, 16)])
+def test_solve_matches_oracle(reg, bc, m, n, k):
+    from ma_amd import engine as E
+    from oracle import drivers as od
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    imgs, u0, omega, h, A, b, T_u, gs = _setup(m, n, k, reg, bc)
+    mu = 0.2 if reg == "tv" else 20.0
+    nu, tau, sigma = 2.0 * k, 0.3 if reg == "tv" else 0.12, 0.3 if reg == "tv" else 0.12
+    kmn = k * m * n
+    ncomp = 6 if reg == "tv" else 4
+    rng = np.random.default_rng(5)
+    x0 = np.concatenate([u0.reshape(-1), 0.5 * T_u.reshape(-1, order="F")])
+    y0 = 0.01 * rng.standard_normal(ncomp * kmn)
+    Fh = lambda y, c, nargout: od.mf_nn_F(y, b, k, h, mu, nu, sigma, c, nargout, reg)
+    Gh = lambda x, c, nargout: od.mf_nn_G(x, (m, n, k), c, nargout)
+    iters = 20
+    xr, yr, phr, dhr = cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, sigma, iters, 1e-3)
+
+    model = E.MODEL_MF_NN_TV if reg == "tv" else E.MODEL_MF_NN_CURV
+    eng = E.Engine(model, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu)
+    eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+    eng.set_primal(x0)
+    eng.linearize()
+    Tg, gg, bg = eng.get_linearization()
+    assert _rel(bg, b) < 1e-14
+    assert _rel(Tg, T_u.reshape(-1, order="F")) < 1e-14
+    eng.set_dual(y0)
+    eng.set_nu(nu)
+    res = eng.solve(1.0, tau, sigma, iters, 1e-3)
+    x, y = eng.primal(), eng.dual()
+    ph, dh = eng.history()
+    eng.close()
+    assert ph.shape == phr.shape and dh.shape == dhr.shape
+    print("x", _rel(x, xr), "y", _rel(y, yr))
+    for c in range(7):
+        print("col", c, np.max(np.abs(ph[:, c] - phr[:, c])), np.max(np.abs(phr[:, c])),
+              np.max(np.abs(dh[:, c] - dhr[:, c])), np.max(np.abs(dhr[:, c])))
+    assert _rel(x[: 2 * kmn], xr[: 2 * kmn]) < TOL      # displacement field
+    assert _rel(x, xr) < TOL
+    assert _rel(y, yr) < TOL
+    assert abs(ph[-1, 0] - phr[-1, 0]) <= TOL * abs(phr[-1, 0])          # final energy
+    np.testing.assert_allclose(ph[:, :5], phr[:, :5], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(dh[:, :5], dhr[:, :5], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(ph[:, 5:], phr[:, 5:], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(dh[:, 5:], dhr[:, 5:], rtol=1e-6, atol=1e-9)
