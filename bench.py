@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Benchmark of the headline workload: CP iterations/s of the NN-TV registration hot path
+(mf_nn_tv_registration_no_ref_ml inner iteration, finest level) at 4096^2 x K=16, fp64.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full Chambolle-Pock iteration (dual pass, K x K eigensolve, primal pass, history row).
+Prints ONE JSON line (rank 0). See DESIGN.md section "Measurement" for the byte accounting.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic elements per pixel-image per CP iteration, SURVEY.md section 8(d)
+ELEMS_ITER = {"tv": 37, "curvature": 31}
+ELEMS_DUAL = {"tv": 21, "curvature": 17}     # dual pass: reads x(3)+x_old(3)+p(6|4)+grad(2)+b(1), writes p(6|4)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--reg", default="tv", choices=["tv", "curvature"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=192)
+    ap.add_argument("--cpu-iters", type=int, default=6)
+    return ap.parse_args()
+
+
+def cpu_baseline(size, k, iters, reg):
+    """The numpy/scipy oracle (a port of the reference's MATLAB path, reference-shaped: assembled sparse A,
+    4 SpMV + 3 SVD of the mn x K matrix per iteration) timed on a bounded sample of the same workload."""
+    from ma_amd import synth
+    from oracle import drivers as od
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    m = n = size
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    u0 = synth.smooth_displacement(m, n, k, amp=2.0).numpy().reshape(k, 2, n * m)
+    u0_ref = np.transpose(u0, (2, 1, 0))
+    omega = [0.0, float(m), 0.0, float(n)]
+    h = (1.0, 1.0)
+    A, b, T_u, _ = od.mf_nn_problem([imgs[i] for i in range(k)], u0_ref, h, omega, reg, "neumann")
+    mu, nu, tau, sigma = 0.2, 0.9 * 2.0 * k, 0.3, 0.3
+    kmn = k * m * n
+    x0 = np.concatenate([u0.reshape(-1), T_u.reshape(-1, order="F")])
+    y0 = np.zeros((6 if reg == "tv" else 4) * kmn)
+    Fh = lambda y, c, nargout: od.mf_nn_F(y, b, k, h, mu, nu, sigma, c, nargout, reg)
+    Gh = lambda x, c, nargout: od.mf_nn_G(x, (m, n, k), c, nargout)
+    t0 = time.perf_counter()
+    cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, sigma, iters, 0.0)
+    dt = time.perf_counter() - t0
+    its = iters / dt
+    return its, dt
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    from ma_amd import engine as E, synth
+    from ma_amd import slab
+
+    m = n = args.size
+    k = args.k
+    reg = args.reg
+    dev = torch.device("cuda", local_rank)
+    model = E.MODEL_MF_NN_TV if reg == "tv" else E.MODEL_MF_NN_CURV
+
+    # deterministic synthetic inputs (no RNG): frames generated on the GPU, handed over as host buffers
+    imgs = synth.dynamic_test_image(m, n, k, device=dev)                      # (k, m, n)
+    imgs_host = imgs.transpose(1, 2).contiguous().cpu().numpy().reshape(-1)   # k stacked column-major images
+    del imgs
+    u0 = synth.smooth_displacement(m, n, k, amp=2.0, device=dev)              # [k][2][n][m]
+    torch.cuda.empty_cache()
+
+    part = slab.Partition(n, world, rank)
+    solver = slab.SlabSolver(model, m, n, k, bc="neumann", h=(1.0, 1.0), omega=[0.0, float(m), 0.0, float(n)],
+                             mu=0.2, device=local_rank, part=part)
+    solver.set_images(imgs_host)
+    del imgs_host
+    # x0 = [u0; L0 = 0]; p0 = 0
+    u0_loc = u0[:, :, part.j0:part.j1, :].contiguous().cpu().numpy().reshape(-1)
+    del u0
+    torch.cuda.empty_cache()
+    x0 = np.concatenate([u0_loc, np.zeros(k * m * part.nl)])
+    solver.set_primal(x0)
+    del x0, u0_loc
+    solver.linearize()
+    nu = 0.9 * float(np.sum(solver.singular_values(0)))        # NNE/mf_nn_tv...:173-175
+    solver.set_nu(nu)
+    est, n_power = solver.norm_estimate()
+    tau = sigma = math.sqrt(0.99 / est ** 2)                   # :195-196
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    solver.iterate(1.0, tau, sigma, max(args.warmup, 1))
+    solver.sync()
+    solver.kernel_times()                                      # drop warm-up timings
+    barrier()
+    t0 = time.perf_counter()
+    solver.iterate(1.0, tau, sigma, args.steps)
+    solver.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    times = solver.kernel_times()
+
+    if rank == 0:
+        kmn_total = float(k) * m * n
+        its = args.steps / dt
+        bytes_iter = ELEMS_ITER[reg] * 8.0 * kmn_total
+        dual_ms, dual_n = times["dual"]
+        dual_avg_s = dual_ms / max(dual_n, 1) * 1e-3
+        # the dominant kernel processes this rank's slab; algorithmic bytes per launch = 21 elements x 8 B x pixel-images
+        dual_bytes = ELEMS_DUAL[reg] * 8.0 * float(k) * m * part.nl
+        achieved = dual_bytes / dual_avg_s / 1e9 if dual_avg_s > 0 else 0.0
+        out = {
+            "metric": "CP iterations/sec, NN-TV registration 4096^2 x K=16" if (reg == "tv" and m == 4096 and k == 16)
+            else f"CP iterations/sec, NN-{reg} registration {m}^2 x K={k}",
+            "value": its,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"mf_nn_{reg}_registration_no_ref_ml inner CP iteration, finest level, "
+                                   f"{m}x{n}, K={k}, fp64, bc=neumann, theta=1, mu=0.2, nu from schedule, tau=sigma from "
+                                   f"power iteration ({n_power} its)",
+                       "parallelism": f"row slabs x{world}" if world > 1 else "single GPU",
+                       "achieved_GBps_algorithmic": bytes_iter * its / 1e9,
+                       "frac_of_hbm_peak": bytes_iter * its / 1e9 / (HBM_PEAK_GBS * world),
+                       "kernel_ms": {kname: (v[0] / max(v[1], 1)) for kname, v in times.items()}},
+            "roofline": {"bound": "hbm", "kernel": f"k_mf_dual<0,{0 if reg == 'tv' else 1}>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+        }
+        if not args.no_cpu_baseline:
+            cits, cdt = cpu_baseline(args.cpu_size, k, args.cpu_iters, reg)
+            scale = (args.cpu_size * args.cpu_size) / float(m * n)
+            out["cpu_baseline"] = {
+                "value": cits * scale, "unit": "iterations/s", "cores": int(os.environ.get("OMP_NUM_THREADS", "1")),
+                "kind": "port",
+                "sample": f"numpy/scipy oracle (reference-shaped: sparse A, 4 SpMV + 3 SVD per iteration), "
+                          f"{args.cpu_iters} CP iterations at {args.cpu_size}^2 x K={k} in {cdt:.1f} s, scaled by pixel "
+                          f"count to {m}^2"}
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

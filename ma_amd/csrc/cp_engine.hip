@@ -147,9 +147,13 @@ static int ensure_hist(cp_engine *h, int rows) {
     return CP_OK;
 }
 
+// grid of the full-domain passes: grid-stride over 256-pixel chunks with at most one resident wave of blocks
+// (256 CUs x blocks per CU admitted by the kernels' register/LDS budget), so that no partial last wave of blocks
+// leaves CUs idle and the partial buffers stay small.
 static int grid_for(const cp_engine *h) {
     const int need = (h->npix + CP_BLOCK - 1) / CP_BLOCK;
-    return std::max(1, std::min(need, 2048));
+    const int resident = 256 * (h->mf ? 3 : 8);
+    return std::max(1, std::min(need, resident));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -511,14 +515,14 @@ static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int
         launch_mf_dual<0>(h, P, h->X[cur], h->X[nxt], h->P[cur], h->P[nxt], h->W[cur], cur, nxt);
         CPCHK(timer_end(h, T_DUAL));
         CPCHK(timer_begin(h, T_EIG));
-        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, eig_args(h, P, n - 1, n, check, 0, 0, tol),
+        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, n - 1, n, check, 0, 0, tol),
                            h->part, ctrl, h->W[nxt], h->hist_p, h->hist_d);
         CPCHK(timer_end(h, T_EIG));
         CPCHK(timer_begin(h, T_PRIMAL));
         launch_mf_primal<0>(h, P, h->X[cur], h->X[nxt], h->P[nxt], h->W[nxt], cur);
         CPCHK(timer_end(h, T_PRIMAL));
         CPCHK(timer_begin(h, T_FIN));
-        hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_BLOCK), 0, h->stream, eig_args(h, P, n, n, 0, 1, nxt, tol),
+        hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, n, n, 0, 1, nxt, tol),
                            h->part, ctrl, h->hist_p, h->hist_d);
         CPCHK(timer_end(h, T_FIN));
     }
@@ -557,10 +561,10 @@ static int solve_mf(cp_engine *h, double theta, double tau, double sigma, int ma
     CPCHK(mf_begin(h));
     // row 0: primal_objective(x0), dual_objective(y0)          chambolle_pock.m:89-106
     launch_mf_dual<1>(h, P, h->X[0], h->X[1], h->P[0], nullptr, h->W[0], 0, 1);
-    hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, eig_args(h, P, 0, 0, 0, 0, 0, tol, 1), h->part, ctrl,
+    hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, 0, 0, 0, 0, 0, tol, 1), h->part, ctrl,
                        h->W[2], h->hist_p, h->hist_d);
     launch_mf_primal<1>(h, P, h->X[0], nullptr, h->P[0], h->W[0], 0);
-    hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_BLOCK), 0, h->stream, eig_args(h, P, 0, 0, 0, 0, 0, tol), h->part, ctrl,
+    hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, 0, 0, 0, 0, 0, tol), h->part, ctrl,
                        h->hist_p, h->hist_d);
     HIPCHK(hipGetLastError());
     int done = 0, stopped = 0, stop_iter = -1;
@@ -580,7 +584,7 @@ static int solve_mf(cp_engine *h, double theta, double tau, double sigma, int ma
         // the reference breaks on i == maxIter before evaluating the rule (chambolle_pock.m:137).
         const int cur = maxIter & 1;
         launch_mf_dual<1>(h, P, h->X[cur], h->X[cur ^ 1], h->P[cur], nullptr, h->W[cur], cur, cur ^ 1);
-        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, eig_args(h, P, maxIter, -1, 0, 0, 0, tol),
+        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, maxIter, -1, 0, 0, 0, tol),
                            h->part, ctrl, h->W[2], h->hist_p, h->hist_d);
         HIPCHK(hipGetLastError());
     }

@@ -48,25 +48,33 @@ enum { DM_Y1 = CP_NSUM, DM_S1 };                                          // dua
 enum { PS_UX = 0, PS_UY, PS_WX };                                         // primal pass sums
 enum { PM_WXMAX = CP_NSUM, PM_WXMIN, PM_WYMAX, PM_WYMIN, PM_VL };         // primal pass maxima
 
-// y3 = y3~ * W for the wave's pixel: loads the K stored values, multiplies by the K x K matrix W (uniform,
-// scalar loads) and leaves the result in tile[k][lane]; returns sum_k y3[k].
+// y3 = y3~ * W for the wave's pixel: loads the K stored values, multiplies by the K x K matrix W (staged in LDS,
+// broadcast reads) and leaves the result in tile[k][lane]; returns sum_k y3[k].
 __device__ __forceinline__ double load_y3_apply_W(const double *__restrict__ y3base, int fs, int e, bool valid,
-                                                  int K, const double *__restrict__ W, double *tile, int lane) {
-    double t3[CP_KMAX];
+                                                  int K, const double *Wl, double *tile, int lane) {
+    double a[CP_KMAX];
 #pragma unroll
-    for (int k = 0; k < CP_KMAX; ++k) t3[k] = (valid && k < K) ? y3base[(size_t)k * fs + e] : 0.0;
+    for (int kp = 0; kp < CP_KMAX; ++kp) a[kp] = 0.0;
+#pragma unroll
+    for (int k = 0; k < CP_KMAX; ++k) {
+        if (k < K) {
+            const double t = valid ? y3base[(size_t)k * fs + e] : 0.0;
+#pragma unroll
+            for (int kp = 0; kp < CP_KMAX; ++kp) a[kp] = fma(t, Wl[k * CP_KMAX + kp], a[kp]);
+        }
+    }
     double s = 0.0;
 #pragma unroll
     for (int kp = 0; kp < CP_KMAX; ++kp) {
-        double a = 0.0;
-        if (kp < K) {
-#pragma unroll
-            for (int k = 0; k < CP_KMAX; ++k) a = fma(t3[k], W[k * CP_KMAX + kp], a);
-        }
-        tile[kp * CP_TS + lane] = a;
-        s += a;
+        tile[kp * CP_TS + lane] = a[kp];
+        s += a[kp];
     }
     return s;
+}
+
+// stage the 16 x 16 matrix W (global) into LDS; the caller synchronises
+__device__ __forceinline__ void stage_W(const double *__restrict__ W, double *Wl) {
+    Wl[threadIdx.x] = W[threadIdx.x];   // CP_BLOCK == 256 entries
 }
 
 // MODE 0: update (writes pout); MODE 1: monitor only (y_new := y_in, nothing written but the partials).
@@ -80,11 +88,14 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
                                                       int cbuf_c, int cbuf_o, double *__restrict__ part) {
     __shared__ double tiles[CP_WAVES * 16 * CP_TS];
     __shared__ double red[CP_WAVES * CP_NSCAL];
+    __shared__ double Wl[CP_KMAX * CP_KMAX];
     if (ctrl->stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *tile = tiles + wave * 16 * CP_TS;
     const int K = P.K, m = P.m, fs = P.fs;
     const bool linear = (P.bc == 1), neumann = (P.bc == 0);
+    stage_W(W, Wl);
+    __syncthreads();
     const double ccx = ctrl->c[cbuf_c][0], ccy = ctrl->c[cbuf_c][1];
     const double cox = ctrl->c[cbuf_o][0], coy = ctrl->c[cbuf_o][1];
     const double sigma = P.sigma, theta = P.theta, inv_sigma = 1.0 / P.sigma;
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
         const bool last_i = (i == m - 1), last_j = (jg == P.n_global - 1);
         const bool first_i = (i == 0), first_j = (jg == 0);
 
-        load_y3_apply_W(y3in, fs, e, valid, K, W, tile, lane);
+        load_y3_apply_W(y3in, fs, e, valid, K, Wl, tile, lane);
 
         double sumLbar = 0.0;
         for (int k = 0; k < K; ++k) {
@@ -269,11 +280,14 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const double
                                                         double *__restrict__ part) {
     __shared__ double tiles[CP_WAVES * 16 * CP_TS];
     __shared__ double red[CP_WAVES * CP_NSCAL];
+    __shared__ double Wl[CP_KMAX * CP_KMAX];
     if (ctrl->stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *tile = tiles + wave * 16 * CP_TS;
     const int K = P.K, m = P.m, fs = P.fs;
     const bool linear = (P.bc == 1), neumann = (P.bc == 0);
+    stage_W(W, Wl);
+    __syncthreads();
     const double ccx = ctrl->c[cbuf_c][0], ccy = ctrl->c[cbuf_c][1];
     const double tau = P.tau;
     const int NY2 = (REG == 0) ? 4 : 2;
@@ -294,7 +308,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const double
         const int e = q + m;
         const int jg = P.j_off + j;
 
-        const double s3 = load_y3_apply_W(y3, fs, e, valid, K, W, tile, lane);
+        const double s3 = load_y3_apply_W(y3, fs, e, valid, K, Wl, tile, lane);
         const double mean3 = s3 * P.invK;
         double sumL = 0.0;
         for (int k = 0; k < K; ++k) {

@@ -17,25 +17,47 @@ struct EigArgs {
 };
 
 // ---- reduction of the per-block partial buffer (fixed order => deterministic) -------------------
+// Runs with CP_RED_THREADS (1024) threads: 4 groups x 256 Gram entries, each group striding the blocks with 8
+// independent accumulators (loads in flight), then a fixed-order combine through LDS. The 16 scalars use
+// 64 sub-groups of 16 threads. stage: LDS scratch of at least 1024 doubles.
+#define CP_RED_THREADS 1024
 __device__ __forceinline__ void reduce_partials(const double *__restrict__ part, int nblk, double (*G)[17],
-                                                double *sc) {
+                                                double *sc, double *stage) {
     const int t = threadIdx.x;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int bI = 0;
-    const double *src = part + CP_NSCAL + t;
-    for (; bI + 4 <= nblk; bI += 4) {
-        a0 += src[(size_t)(bI + 0) * CP_PSTRIDE];
-        a1 += src[(size_t)(bI + 1) * CP_PSTRIDE];
-        a2 += src[(size_t)(bI + 2) * CP_PSTRIDE];
-        a3 += src[(size_t)(bI + 3) * CP_PSTRIDE];
+    {
+        const int grp = t >> 8, e = t & 255;
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = 0.0;
+        const double *src = part + CP_NSCAL + e;
+        int bI = grp;
+        for (; bI + 28 < nblk; bI += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += src[(size_t)(bI + 4 * u) * CP_PSTRIDE];
+        }
+        for (int u = 0; bI < nblk; bI += 4, ++u) a[u & 7] += src[(size_t)bI * CP_PSTRIDE];
+        stage[t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
-    for (; bI < nblk; ++bI) a0 += src[(size_t)bI * CP_PSTRIDE];
-    G[t >> 4][t & 15] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (t < 256) G[t >> 4][t & 15] = (stage[t] + stage[256 + t]) + (stage[512 + t] + stage[768 + t]);
+    __syncthreads();
+    {
+        const int slot = t & 15, sub = t >> 4;   // 64 sub-groups
+        const bool is_sum = slot < CP_NSUM;
+        double v = is_sum ? 0.0 : -1.0e300;
+        for (int bI = sub; bI < nblk; bI += 64) {
+            const double o = part[(size_t)bI * CP_PSTRIDE + slot];
+            v = is_sum ? v + o : fmax(v, o);
+        }
+        stage[t] = v;
+    }
+    __syncthreads();
     if (t < CP_NSCAL) {
-        double v = part[t];
-        for (int bb = 1; bb < nblk; ++bb) {
-            const double o = part[(size_t)bb * CP_PSTRIDE + t];
-            v = (t < CP_NSUM) ? v + o : fmax(v, o);
+        const bool is_sum = t < CP_NSUM;
+        double v = stage[t];
+        for (int sub = 1; sub < 64; ++sub) {
+            const double o = stage[sub * 16 + t];
+            v = is_sum ? v + o : fmax(v, o);
         }
         sc[t] = v;
     }
@@ -47,13 +69,13 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
 // eigenvalues and (WITH_V) the columns of V the eigenvectors: G_in = V diag V'.
 template <bool WITH_V>
 __device__ void jacobi16(double (*G)[17], double (*V)[17], double (*cs)[2], int (*pq)[2], int *rotflag) {
-    const int t = threadIdx.x;
-    if (WITH_V) V[t >> 4][t & 15] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
+    const int t = threadIdx.x;   // the first 256 threads work, the others only join the barriers
+    if (WITH_V && t < 256) V[t >> 4][t & 15] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
     {   // symmetrise
-        const int r = t >> 4, c = t & 15;
+        const int r = (t >> 4) & 15, c = t & 15;
         const double s = 0.5 * (G[r][c] + G[c][r]);
         __syncthreads();
-        G[r][c] = s;
+        if (t < 256) G[r][c] = s;
     }
     __syncthreads();
     for (int sweep = 0; sweep < 30; ++sweep) {
@@ -85,7 +107,7 @@ __device__ void jacobi16(double (*G)[17], double (*V)[17], double (*cs)[2], int 
                     const double gp = G[l][p], gq = G[l][q];
                     G[l][p] = c * gp - s * gq;
                     G[l][q] = s * gp + c * gq;
-                } else if (WITH_V) {
+                } else if (WITH_V && t < 256) {
                     const double vp = V[l][p], vq = V[l][q];
                     V[l][p] = c * vp - s * vq;
                     V[l][q] = s * vp + c * vq;
@@ -109,13 +131,13 @@ __device__ void jacobi16(double (*G)[17], double (*V)[17], double (*cs)[2], int 
 }
 
 // ---- dual-side finalisation: W for y3, F* values, primal row rp, stop rule ------------------------
-__global__ __launch_bounds__(CP_BLOCK) void k_mf_eig(EigArgs A, const double *__restrict__ part, CpCtrl *ctrl,
-                                                     double *__restrict__ Wout, double *hist_p, double *hist_d) {
-    __shared__ double G[16][17], V[16][17], sc[CP_NSCAL], cs[8][2], dvec[16];
+__global__ __launch_bounds__(CP_RED_THREADS) void k_mf_eig(EigArgs A, const double *__restrict__ part, CpCtrl *ctrl,
+                                                           double *__restrict__ Wout, double *hist_p, double *hist_d) {
+    __shared__ double G[16][17], V[16][17], sc[CP_NSCAL], cs[8][2], dvec[16], stage[CP_RED_THREADS];
     __shared__ int pq[8][2], rotflag;
     if (ctrl->stop) return;
     const int t = threadIdx.x;
-    reduce_partials(part, A.nblk, G, sc);
+    reduce_partials(part, A.nblk, G, sc, stage);
     jacobi16<true>(G, V, cs, pq, &rotflag);
     if (t == 0) {
         const int K = A.K;
@@ -186,7 +208,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_eig(EigArgs A, const double *__
         }
     }
     __syncthreads();
-    {   // W = I - V diag(d) V'
+    if (t < 256) {   // W = I - V diag(d) V'
         const int k = t >> 4, kp = t & 15;
         double a = (k == kp) ? 1.0 : 0.0;
 #pragma unroll
@@ -196,19 +218,19 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_eig(EigArgs A, const double *__
 }
 
 // ---- primal-side finalisation: offsets c, feasibility of B*L, G* measures, dual row rd ------------
-__global__ __launch_bounds__(CP_BLOCK) void k_mf_fin(EigArgs A, const double *__restrict__ part, CpCtrl *ctrl,
-                                                     double *hist_p, double *hist_d) {
-    __shared__ double G[16][17], sc[CP_NSCAL], cs[8][2];
+__global__ __launch_bounds__(CP_RED_THREADS) void k_mf_fin(EigArgs A, const double *__restrict__ part, CpCtrl *ctrl,
+                                                           double *hist_p, double *hist_d) {
+    __shared__ double G[16][17], sc[CP_NSCAL], cs[8][2], stage[CP_RED_THREADS];
     __shared__ int pq[8][2], rotflag;
     if (ctrl->stop) return;
-    reduce_partials(part, A.nblk, G, sc);
+    reduce_partials(part, A.nblk, G, sc, stage);
     {
         // B*L is exactly mean-free over the images, so (1,..,1) is a null vector of its Gram matrix. Rounding would
         // turn that zero into sqrt(eps)*s_max; restrict the matrix to the orthogonal complement instead
         // (Helmert basis q_j = (1,..,1,-j,0,..)/sqrt(j(j+1)), j = 1..K-1) before the eigensolve.
-        const int t = threadIdx.x, a = t >> 4, bq = t & 15, K = A.K;
+        const int t = threadIdx.x, a = (t >> 4) & 15, bq = t & 15, K = A.K;
         double acc = 0.0;
-        if (a < K - 1 && bq < K - 1) {
+        if (t < 256 && a < K - 1 && bq < K - 1) {
             const double na = 1.0 / sqrt((double)(a + 1) * (a + 2)), nb = 1.0 / sqrt((double)(bq + 1) * (bq + 2));
             for (int i = 0; i <= a + 1; ++i) {
                 const double qa = (i <= a) ? na : -(double)(a + 1) * na;
@@ -221,7 +243,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_fin(EigArgs A, const double *__
             }
         }
         __syncthreads();
-        G[a][bq] = acc;
+        if (t < 256) G[a][bq] = acc;
         __syncthreads();
     }
     jacobi16<false>(G, nullptr, cs, pq, &rotflag);
@@ -259,16 +281,19 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_materialize(MfParams P, const d
                                                              double *__restrict__ pd, const double *__restrict__ W,
                                                              const CpCtrl *__restrict__ ctrl, int cbuf) {
     __shared__ double tiles[CP_WAVES * 16 * CP_TS];
+    __shared__ double Wl[CP_KMAX * CP_KMAX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *tile = tiles + wave * 16 * CP_TS;
     const int K = P.K, fs = P.fs;
+    stage_W(W, Wl);
+    __syncthreads();
     const double cx = ctrl->c[cbuf][0], cy = ctrl->c[cbuf][1];
     const int NY2 = (REG == 0) ? 4 : 2;
     for (int base = blockIdx.x * CP_BLOCK; base < P.npix; base += gridDim.x * CP_BLOCK) {
         const int q = base + tid;
         const bool valid = q < P.npix;
         const int e = q + P.m;
-        load_y3_apply_W(ps + (size_t)(K + NY2 * K) * fs, fs, e, valid, K, W, tile, lane);
+        load_y3_apply_W(ps + (size_t)(K + NY2 * K) * fs, fs, e, valid, K, Wl, tile, lane);
         if (valid) {
             for (int k = 0; k < K; ++k) {
                 xd[(size_t)(2 * k) * fs + e] = xs[(size_t)(2 * k) * fs + e] - cx;

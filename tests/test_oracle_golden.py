@@ -1,0 +1,56 @@
+"""The oracle reproduces the committed fixtures (regression pin; see tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+
+from oracle import drivers as od, operators as oo, prox as px
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_operator_fixture(golden_dir):
+    f = _load(golden_dir, "operators.npz")
+    m, n, k = [int(v) for v in f["shape"]]
+    h = tuple(f["h"])
+    for bc in ("neumann", "linear"):
+        D = oo.finite_difference_operator(m, n, h, k, bc)
+        assert np.array_equal(D @ f["x_u"], f[f"D_{bc}_x"])
+        assert np.array_equal(D.T @ f["y_d"], f[f"Dt_{bc}_y"])
+    for bc in ("neumann", "dirichlet"):
+        assert np.array_equal(oo.discrete_laplacian(m, n, h, k, bc) @ f["x_u"], f[f"Lap_{bc}_x"])
+    mu, sig = float(f["mu"]), float(f["sig"])
+    assert np.allclose(px.SAD(f["Lv"], f["I"], mu, sig, True, 3)[2], f["SAD_cprox"], rtol=0, atol=1e-15)
+    assert np.allclose(px.pointwise_2x2_nn(f["v4"], mu, sig, True, 3)[2], f["nn2_cprox"], rtol=0, atol=1e-14)
+    assert np.allclose(px.norm21(f["v4"], mu, sig, True, 3)[2], f["n21_cprox"], rtol=0, atol=1e-15)
+    U, S, V = px.svd_2x2(f["svd_M"])
+    assert np.allclose(S, f["svd_S"], atol=1e-15) and np.allclose(U, f["svd_U"], atol=1e-14)
+    i = 0
+    while f"l1_in{i}" in f:
+        assert np.allclose(px.l1ball_projection(f[f"l1_in{i}"]), f[f"l1_out{i}"], atol=1e-15)
+        i += 1
+    r = px.nuclear_norm_constraint(f["nnc_Y"], k, float(f["nnc_tau"]), float(f["nnc_nu"]), True, 3)[2]
+    assert np.allclose(r, f["nnc_cprox"], atol=1e-12)
+    r = px.mean_zero_indicator(f["x_u"], (m, n, k), True, 3)
+    assert np.allclose(r[2], f["mzi_cprox"], atol=1e-15) and np.allclose(r[:2], f["mzi_cval"], atol=1e-15)
+
+
+def test_warp_fixture(golden_dir):
+    f = _load(golden_dir, "warp.npz")
+    Tu, g = oo.evaluate_displacement(f["T"], (1.0, 1.0), f["u"])
+    assert np.array_equal(Tu, f["Tu"]) and np.array_equal(g, f["g"])
+    m, n = f["T"].shape
+    Tcu, gc = oo.evaluate_displacement(f["Tc"], tuple(f["hg"]), f["uc"], [0.0, float(m), 0.0, float(n)])
+    assert np.array_equal(Tcu, f["Tcu"]) and np.array_equal(gc, f["gc"])
+
+
+def test_pairwise_first_step_fixture(golden_dir):
+    f = _load(golden_dir, "pairwise_e2e.npz")
+    png = _load(golden_dir, "data_png.npz")
+    R = od.normalize(png["rect_1"].astype(float))
+    T = od.normalize(png["rect_2"].astype(float))
+    lam, tau, iters, _ = f["tvl1_rect_par"]
+    u, v, hist, _ = od.tv_registration(R, T, lam, tau, int(iters), 1, "SAD", keep_histories=True)
+    assert np.allclose(u, f["tvl1_rect_s0_u"], atol=1e-12)
+    assert np.allclose(hist[0][0], f["tvl1_rect_s0_ph"], rtol=1e-12, atol=1e-12)

@@ -1,0 +1,166 @@
+"""Pins the CPU oracle with the invariants the reference's own interactive tests check:
+the reference stores no golden vectors, so these properties plus the committed fixtures are what pins parity."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import operators as oo, prox as px
+from oracle.chambolle_pock import chambolle_pock
+
+
+def test_interpolation_at_nodes_reproduces_image():
+    # IRE/test_interpolation.m:39-42
+    rng = np.random.default_rng(0)
+    img = rng.random((13, 17))
+    out, g = oo.evaluate_displacement(img, (1.0, 1.0), np.zeros((13 * 17, 2)))
+    assert np.max(np.abs(out - img)) == 0.0
+    out, g = oo.evaluate_displacement(img, (0.7, 1.3), np.zeros((13 * 17, 2)))
+    assert np.max(np.abs(out - img)) < 1e-13
+
+
+def test_interpolation_zero_padding_and_derivative():
+    rng = np.random.default_rng(1)
+    img = rng.random((6, 5))
+    p = np.array([[-3.0, 2.0], [2.2, 100.0], [3.3, 2.7]])
+    v, d = oo.bilinear_interpolation(img, (1.0, 1.0), p)
+    assert v[0] == 0.0 and v[1] == 0.0 and np.all(d[:2] == 0.0)
+    eps = 1e-6
+    vp, _ = oo.bilinear_interpolation(img, (1.0, 1.0), p[2:] + [[eps, 0.0]])
+    vm, _ = oo.bilinear_interpolation(img, (1.0, 1.0), p[2:] - [[eps, 0.0]])
+    assert abs((vp - vm)[0] / (2 * eps) - d[2, 0]) < 1e-8
+
+
+def test_svd_2x2_reconstruction():
+    # NNE/svd_2x2.m:52-56
+    rng = np.random.default_rng(2)
+    M = rng.standard_normal((200, 4))
+    U, S, V = px.svd_2x2(M)
+    R = np.stack([S[:, 0] * U[:, 0] * V[:, 0] + S[:, 1] * U[:, 2] * V[:, 2],
+                  S[:, 0] * U[:, 1] * V[:, 0] + S[:, 1] * U[:, 3] * V[:, 2],
+                  S[:, 0] * U[:, 0] * V[:, 1] + S[:, 1] * U[:, 2] * V[:, 3],
+                  S[:, 0] * U[:, 1] * V[:, 1] + S[:, 1] * U[:, 3] * V[:, 3]], axis=1)
+    assert np.max(np.abs(R - M)) < 1e-13
+    # singular values agree with LAPACK
+    for r in range(20):
+        s = np.linalg.svd(np.array([[M[r, 0], M[r, 2]], [M[r, 1], M[r, 3]]]), compute_uv=False)
+        assert np.allclose(S[r], s, atol=1e-13)
+
+
+def test_svd_2x2_degenerate_rows_follow_reference_formulas():
+    # atan2(0,0) = 0 and sign(0) = 0: the zero matrix yields V = 0 (NNE/svd_2x2.m:36-43)
+    U, S, V = px.svd_2x2(np.zeros((1, 4)))
+    assert np.all(S == 0) and np.all(V == 0) and np.allclose(U, [[1, 0, 0, 1]])
+
+
+def test_l1ball_projection_properties():
+    # NNE/test_l1ball_projection.m:45-56
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 5, 16, 200):
+        x = rng.standard_normal(n) * 3
+        y = px.l1ball_projection(x)
+        if np.sum(np.abs(x)) <= 1:
+            assert np.array_equal(x, y)
+        else:
+            assert abs(np.sum(np.abs(y)) - 1) < 1e-12
+            assert np.allclose(px.l1ball_projection(y), y, atol=1e-14)          # idempotent
+            # nearest point: no feasible random point is closer
+            for _ in range(50):
+                z = rng.standard_normal(n)
+                z = z / max(np.sum(np.abs(z)), 1.0)
+                assert np.linalg.norm(x - y) <= np.linalg.norm(x - z) + 1e-12
+    # sort-based characterisation (Duchi et al.)
+    x = np.abs(rng.standard_normal(16)) * 2
+    s = np.sort(x)[::-1]
+    cs = np.cumsum(s)
+    rho = np.max(np.nonzero(s - (cs - 1) / np.arange(1, 17) > 0)[0]) + 1
+    theta = (cs[rho - 1] - 1) / rho
+    assert np.allclose(px.l1ball_projection(x), np.maximum(x - theta, 0), atol=1e-14)
+
+
+def test_chambolle_pock_quadratic_known_answer():
+    # PDO/test_chambolle_pock.m:16-41 : min 0.5||Kx||^2 + 0.5*lambda*||x - g||^2, x* = (K'K + lambda I)^-1 lambda g
+    rng = np.random.default_rng(4)
+    n = 40
+    K = sp.csr_matrix(rng.integers(-2, 3, size=(n, n)).astype(float))
+    g = rng.standard_normal(n)
+    lam = 5.0
+    L = np.linalg.norm(K.toarray(), 2)
+    tau = sigma = 0.99 / L
+
+    def F(v, conj, nargout):
+        if not conj:
+            return 0.5 * v @ v, 0.0, (v / (1 + sigma) if nargout == 3 else None)
+        return 0.5 * v @ v, 0.0, (v / (1 + sigma) if nargout == 3 else None)
+
+    def G(x, conj, nargout):
+        if not conj:
+            return 0.5 * lam * np.sum((x - g) ** 2), 0.0, ((x + tau * lam * g) / (1 + tau * lam) if nargout == 3 else None)
+        return 0.5 / lam * (x @ x) + x @ g, 0.0, None
+
+    x, y, ph, dh = chambolle_pock(F, G, K, np.zeros(n), np.zeros(n), 1.0, tau, sigma, 3000, 1e-10)
+    xs = np.linalg.solve(K.T.toarray() @ K.toarray() + lam * np.eye(n), lam * g)
+    assert np.linalg.norm(x - xs) < 1e-4 * np.linalg.norm(xs)
+    assert abs(ph[-1, 0] - dh[-1, 0]) < 1e-6 * abs(dh[-1, 0])      # primal and dual energies meet
+
+
+@pytest.mark.parametrize("name", ["SAD", "SSD", "norm21", "pointwise_2x2_nn"])
+def test_moreau_identity(name):
+    # prox_{sigma F}(v) + sigma * prox_{F*/sigma}(v/sigma) = v
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(4 * 30) * 2
+    I = rng.standard_normal(4 * 30)
+    mu, sigma = 0.6, 0.35
+    if name in ("SAD", "SSD"):
+        f = getattr(px, name)
+        a = f(v, I, mu, sigma, False, 3)[2]
+        b = f(v / sigma, I, mu, 1 / sigma, True, 3)[2]
+    else:
+        f = getattr(px, name)
+        a = f(v, mu, sigma, False, 3)[2]
+        b = f(v / sigma, mu, 1 / sigma, True, 3)[2]
+    assert np.allclose(a + sigma * b, v, atol=1e-12)
+
+
+def test_operators_adjoint_and_structure():
+    m, n, k = 7, 5, 2
+    h = (0.5, 2.0)
+    rng = np.random.default_rng(6)
+    for bc in ("neumann", "linear"):
+        D = oo.finite_difference_operator(m, n, h, k, bc)
+        assert D.shape == (4 * k * m * n, 2 * k * m * n)
+        assert np.abs(D @ np.ones(2 * k * m * n)).max() == 0.0        # constants are in the kernel
+    D = oo.finite_difference_operator(m, n, h, 1, "linear").toarray()
+    assert D[m - 1, m - 2] == -1.0 and D[m - 1, m - 1] == 1.0       # unscaled last row (quirk)
+    assert D[0, 0] == -1 / h[0]
+    with pytest.raises(ValueError):
+        oo.finite_difference_operator(m, n, h, 1, "periodic")
+    Ln = oo.discrete_laplacian(m, n, h, k, "neumann")
+    assert abs(Ln - Ln.T).max() == 0 and np.abs(Ln @ np.ones(2 * k * m * n)).max() < 1e-12
+    Ld = oo.discrete_laplacian(m, n, h, 1, "dirichlet").toarray()
+    assert Ld[0, 0] == -2 / h[0] ** 2 - 2 / h[1] ** 2
+    B = oo.mean_free_operator(m, n, 3)
+    x = rng.standard_normal(3 * m * n)
+    assert np.allclose(B @ (B @ x), B @ x) and abs(B - B.T).max() < 1e-16
+    assert np.abs((B @ x).reshape(3, -1).sum(axis=0)).max() < 1e-14
+
+
+def test_matrix_norm_matches_dense_norm():
+    rng = np.random.default_rng(7)
+    S = sp.csr_matrix(rng.standard_normal((30, 20)))
+    e = oo.matrix_norm(S, x0=np.ones(20))
+    assert abs(e[-1] - np.linalg.norm(S.toarray(), 2)) < 1e-3 * e[-1]
+    assert 2 <= len(e) <= 100
+
+
+def test_pyramid_and_prolongation():
+    a = np.arange(35, dtype=float).reshape(5, 7)
+    d = oo.downsample(a)
+    assert d.shape == (3, 4)
+    assert d[0, 0] == 0.25 * (a[0, 0] + a[1, 0] + a[0, 1] + a[1, 1])
+    assert d[2, 3] == 0.25 * a[4, 6]                                   # zero padding past the end
+    x = np.arange(12, dtype=float)
+    p = oo.prolong_fields(x, 3, 4, 5, 7, 1)
+    P = p.reshape((5, 7), order="F")
+    X = x.reshape((3, 4), order="F")
+    assert P[4, 6] == X[2, 3] and P[1, 1] == X[0, 0] and P[2, 1] == X[1, 0]
+    assert oo.num_levels(64, 48) == 1 and oo.num_levels(200, 200) == 3 and oo.num_levels(4096, 4096) == 8
