@@ -22,7 +22,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic elements per pixel-image per CP iteration, SURVEY.md section 8(d)
 ELEMS_ITER = {"tv": 37, "curvature": 31}
-ELEMS_DUAL = {"tv": 21, "curvature": 17}     # dual pass: reads x(3)+x_old(3)+p(6|4)+grad(2)+b(1), writes p(6|4)
+# dominant kernel: NN-TV runs one fused kernel per iteration (k_mf_fused_tv: the whole iteration's 37 elements);
+# NN-curvature runs separate passes, the dual pass (reads x(3)+x_old(3)+p(4)+grad(2)+b(1), writes p(4)) dominates
+ELEMS_DOM = {"tv": 37, "curvature": 17}
+DOM_KERNEL = {"tv": "k_mf_fused_tv<false,true>", "curvature": "k_mf_dual<0,1>"}
 
 
 def parse():
@@ -137,8 +140,8 @@ def main():
         bytes_iter = ELEMS_ITER[reg] * 8.0 * kmn_total
         dual_ms, dual_n = times["dual"]
         dual_avg_s = dual_ms / max(dual_n, 1) * 1e-3
-        # the dominant kernel processes this rank's slab; algorithmic bytes per launch = 21 elements x 8 B x pixel-images
-        dual_bytes = ELEMS_DUAL[reg] * 8.0 * float(k) * m * part.nl
+        # the dominant kernel processes this rank's slab; algorithmic bytes per launch = elements x 8 B x pixel-images
+        dual_bytes = ELEMS_DOM[reg] * 8.0 * float(k) * m * part.nl
         achieved = dual_bytes / dual_avg_s / 1e9 if dual_avg_s > 0 else 0.0
         out = {
             "metric": "CP iterations/sec, NN-TV registration 4096^2 x K=16" if (reg == "tv" and m == 4096 and k == 16)
@@ -161,7 +164,7 @@ def main():
                        "achieved_GBps_algorithmic": bytes_iter * its / 1e9,
                        "frac_of_hbm_peak": bytes_iter * its / 1e9 / (HBM_PEAK_GBS * world),
                        "kernel_ms": {kname: (v[0] / max(v[1], 1)) for kname, v in times.items()}},
-            "roofline": {"bound": "hbm", "kernel": f"k_mf_dual<0,{0 if reg == 'tv' else 1}>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": DOM_KERNEL[reg], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
         }
         if not args.no_cpu_baseline:

@@ -7,10 +7,10 @@
 #define CP_WAVES (CP_BLOCK / 64)
 #define CP_KMAX 16            // max images per mf_nn problem (one 16x16 f64 MFMA tile)
 #define CP_TS 66              // LDS tile row stride (doubles): conflict-free ds_read_b64 in MFMA order
-#define CP_NSUM 8             // per-pass partial sums   (slots 0..7)
-#define CP_NMAX 8             // per-pass partial maxima (slots 8..15)
+#define CP_NSUM 12            // per-pass partial sums   (slots 0..11)
+#define CP_NMAX 8             // per-pass partial maxima (slots 12..19)
 #define CP_NSCAL (CP_NSUM + CP_NMAX)
-#define CP_PSTRIDE (CP_NSCAL + CP_KMAX * CP_KMAX)   // doubles per block in the partial buffer
+#define CP_PSTRIDE (CP_NSCAL + 2 * CP_KMAX * CP_KMAX)   // doubles per block in the partial buffer: scalars + 2 Grams
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 

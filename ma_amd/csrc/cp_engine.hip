@@ -9,7 +9,7 @@
 #include <vector>
 
 #include "../../include/cpengine.h"
-#include "cp_mfnn_small.cuh"
+#include "cp_mfnn_fused.cuh"
 #include "cp_pair.cuh"
 
 static thread_local std::string g_err;
@@ -37,6 +37,7 @@ static thread_local std::string g_err;
     } while (0)
 
 enum { T_DUAL = 0, T_EIG, T_PRIMAL, T_FIN, T_ITER, T_COUNT };
+// for the fused NN-TV path "dual" times k_mf_fused_tv and "eig" times k_mf_efused
 static const char *kPassNames[T_COUNT] = {"dual", "eig", "primal", "fin", "iterate"};
 
 struct PassTimer {
@@ -64,6 +65,7 @@ struct cp_engine {
     int hist_rows = 0;   // rows allocated (per problem)
     int hcols = 0;
     int nblk = 0;
+    int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU: two LDS tiles per wave)
     bool linearized = false, has_nu = false, has_images = false;
     hipStream_t stream = nullptr;
     std::vector<cp_result> last;   // per problem
@@ -243,10 +245,11 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         HIPCHK(hipMalloc(&h->img, sizeof(double) * imgN));
         if (!mf && h->gt != GT_SAD_DEN) HIPCHK(hipMalloc(&h->imgR, sizeof(double) * imgN));
         h->nblk = grid_for(h);
+        h->nblk_fused = std::max(1, std::min((h->npix + CP_BLOCK - 1) / CP_BLOCK, 256 * 2));
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
             HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
-            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)h->nblk * CP_PSTRIDE));
+            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(h->nblk, h->nblk_fused) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->svout, sizeof(double) * (16 + 256 + 256)));
             HIPCHK(hipMalloc(&h->ctrl, sizeof(CpCtrl)));
             HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(CpCtrl), h->stream));
@@ -498,9 +501,11 @@ static void launch_mf_primal(cp_engine *h, const MfParams &P, const double *xc, 
 }
 
 static EigArgs eig_args(const cp_engine *h, const MfParams &P, int rp, int rd, int check, int update, int newbuf,
-                        double tol, int monitor = 0) {
+                        double tol, int monitor = 0, int compute_cn = 0) {
     EigArgs A;
     A.monitor = monitor;
+    A.compute_cn = compute_cn;
+    A.tau = P.tau;
     A.nblk = h->nblk; A.K = h->K; A.reg = h->reg; A.rp = rp; A.rd = rd; A.check_stop = check; A.update = update;
     A.newbuf = newbuf; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2; A.sigma = P.sigma; A.Ntot = P.Ntot;
     return A;
@@ -525,6 +530,40 @@ static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int
         hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, n, n, 0, 1, nxt, tol),
                            h->part, ctrl, h->hist_p, h->hist_d);
         CPCHK(timer_end(h, T_FIN));
+    }
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+
+// ---- fused NN-TV path: F_0 = dual step 1 alone, then one k_mf_fused_tv + k_mf_efused per iteration -------------
+static int mf_fused_start(cp_engine *h, const MfParams &P, double tol) {
+    CpCtrl *ctrl = (CpCtrl *)h->ctrl;
+    launch_mf_dual<0>(h, P, h->X[0], h->X[1], h->P[0], h->P[1], h->W[0], 0, 1);
+    hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, -1, 1, 0, 0, 0, tol, 0, 1),
+                       h->part, ctrl, h->W[1], h->hist_p, h->hist_d);
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+static int mf_fused_iterations(cp_engine *h, const MfParams &P, int n0, int count, int check, double tol) {
+    CpCtrl *ctrl = (CpCtrl *)h->ctrl;
+    for (int n = n0 + 1; n <= n0 + count; ++n) {
+        const int cur = n & 1, prv = (n - 1) & 1, nxt = (n + 1) & 1;   // x_{n-1} in X[prv], y_n in P[cur]
+        CPCHK(timer_begin(h, T_DUAL));
+        {
+            auto kern = (h->d.bc == CP_BC_LINEAR)
+                            ? (h->K == CP_KMAX ? k_mf_fused_tv<true, true> : k_mf_fused_tv<true, false>)
+                            : (h->K == CP_KMAX ? k_mf_fused_tv<false, true> : k_mf_fused_tv<false, false>);
+            hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, h->X[prv], h->X[cur], h->P[cur],
+                               h->P[nxt], h->g, h->b, h->W[cur], (const CpCtrl *)ctrl, h->part);
+        }
+        CPCHK(timer_end(h, T_DUAL));
+        EFusedArgs A;
+        A.nblk = h->nblk_fused; A.K = h->K; A.n = n; A.check_stop = check; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
+        A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot;
+        CPCHK(timer_begin(h, T_EIG));
+        hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, h->part, ctrl, h->W[nxt], h->hist_p,
+                           h->hist_d);
+        CPCHK(timer_end(h, T_EIG));
     }
     HIPCHK(hipGetLastError());
     return CP_OK;
@@ -569,9 +608,12 @@ static int solve_mf(cp_engine *h, double theta, double tau, double sigma, int ma
     HIPCHK(hipGetLastError());
     int done = 0, stopped = 0, stop_iter = -1;
     const int chunk = 32;
+    const bool fused = (h->reg == 0);
+    if (fused && maxIter > 0) CPCHK(mf_fused_start(h, P, tol));
     while (done < maxIter && !stopped) {
         const int cnt = std::min(chunk, maxIter - done);
-        CPCHK(mf_iterations(h, P, done, cnt, 1, tol));
+        if (fused) CPCHK(mf_fused_iterations(h, P, done, cnt, 1, tol));
+        else CPCHK(mf_iterations(h, P, done, cnt, 1, tol));
         done += cnt;
         int hdr[2];
         HIPCHK(hipMemcpyAsync(hdr, ctrl, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
@@ -579,7 +621,7 @@ static int solve_mf(cp_engine *h, double theta, double tau, double sigma, int ma
         stopped = hdr[0];
         stop_iter = hdr[1];
     }
-    if (!stopped) {
+    if (!stopped && !(fused && maxIter > 0)) {
         // primal row maxIter (trails by one kernel) -- and the stop rule may still fire for i = maxIter? No:
         // the reference breaks on i == maxIter before evaluating the rule (chambolle_pock.m:137).
         const int cur = maxIter & 1;
@@ -829,8 +871,14 @@ extern "C" int cp_iterate(cp_handle h, double theta, double tau, double sigma, i
         PassTimer &t = h->timers[T_ITER];
         if (t.used + 2 > t.ev.size())
             for (int a = 0; a < 2; ++a) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); t.ev.push_back(e); }
+        if (h->reg == 0) {
+            h->profile = false;
+            CPCHK(mf_fused_start(h, P, 0.0));
+            h->profile = true;
+        }
         HIPCHK(hipEventRecord(t.ev[t.used], h->stream));
-        CPCHK(mf_iterations(h, P, 0, iters, 0, 0.0));
+        if (h->reg == 0) CPCHK(mf_fused_iterations(h, P, 0, iters, 0, 0.0));
+        else CPCHK(mf_iterations(h, P, 0, iters, 0, 0.0));
         HIPCHK(hipEventRecord(t.ev[t.used + 1], h->stream));
         t.used += 2;
         CPCHK(mf_end(h, P, iters));

@@ -25,7 +25,8 @@ struct CpCtrl {
     int stop;          // set by the stop rule; every later kernel of the solve returns immediately
     int stop_iter;     // i at which the rule fired
     int pad0, pad1;
-    double c[2][2];    // pending mean offsets of the two x buffers: true u = stored - c[buf][comp]
+    double c[2][2];    // pending mean offsets of the two x buffers: true u = stored - c[buf][comp] (split passes)
+    double cn[2];      // mean of the next un-projected u, known before the fused pass runs (see k_mf_fused_tv)
     double nu;         // radius of the nuclear-norm ball
     double sv[CP_KMAX];      // last singular values computed by k_mf_eig (descending not guaranteed)
     double svL[CP_KMAX];     // last singular values of B*L computed by k_mf_fin
@@ -43,10 +44,10 @@ struct MfParams {
 };
 
 // slots of the per-block partial buffer
-enum { DS_F1 = 0, DS_F2, DS_F1S, DS_UX, DS_UY, DS_F2S };                 // dual pass sums
-enum { DM_Y1 = CP_NSUM, DM_S1 };                                          // dual pass maxima
-enum { PS_UX = 0, PS_UY, PS_WX };                                         // primal pass sums
-enum { PM_WXMAX = CP_NSUM, PM_WXMIN, PM_WYMAX, PM_WYMIN, PM_VL };         // primal pass maxima
+enum { DS_F1 = 0, DS_F2, DS_F1S, DS_UX, DS_UY, DS_F2S, DS_SGX, DS_SGY,   // dual-side sums
+       PS_WX, PS_UX, PS_UY };                                             // primal-side sums
+enum { DM_Y1 = CP_NSUM, DM_S1,                                            // dual-side maxima
+       PM_WXMAX, PM_WXMIN, PM_WYMAX, PM_WYMIN, PM_VL };                   // primal-side maxima
 
 // y3 = y3~ * W for the wave's pixel: loads the K stored values, multiplies by the K x K matrix W (staged in LDS,
 // broadcast reads) and leaves the result in tile[k][lane]; returns sum_k y3[k].
@@ -152,6 +153,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
                     y1n = y1;
                 }
                 sums[DS_F1S] += y1n * bb;                             // NNE/SAD.m:83
+                sums[DS_SGX] += gx * y1n;                             // sum of grad T' y1: mean of the next u (fused pass)
+                sums[DS_SGY] += gy * y1n;
                 maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], fabs(y1n));
 
                 // ---- y2 -------------------------------------------------------------------------

@@ -1,0 +1,377 @@
+// NN-TV: one kernel per Chambolle-Pock iteration.
+//
+// k_mf_fused_tv(n) = primal step n followed by dual step n+1 of PDO/chambolle_pock.m:162-165 for the model of
+// NNE/mf_nn_tv_registration_no_ref_ml.m, per pixel, with the state read and written exactly once:
+//     reads  x_{n-1} (3), y_n (6), grad T (2), b (1)          writes x_n (3), y_{n+1} (6)     [per pixel-image]
+// i.e. 21 elements instead of the 35 the separate passes move (the dual pass no longer re-reads x and x_old).
+//
+// What makes the fusion legal:
+//   * the dual step at (i,j) needs x_n at (i,j), (i+1,j), (i,j+1) (forward differences). The displacement part of
+//     the primal step is cheap (adjoint stencil + one fma), so each thread recomputes it at its two neighbours
+//     from y_n, which is never written by this kernel -- no inter-thread exchange, no halo tiles;
+//   * the mean-zero projection (NNE/mean_zero_indicator.m:50-53) subtracts mean(u - tau*(A'y)_u). Since D*1 = 0
+//     for both boundary conditions, mean((A'y)_u) = -mean(grad T' y1), which the PREVIOUS dual step accumulates
+//     while it writes y1; together with the measured mean of the previous u this gives the mean before the pass
+//     starts (ctrl->cn), identical to the reference up to rounding and without drift;
+//   * the nuclear-norm prox of y3 stays lazy (y3 = y3~ * W, W from k_mf_efused of the previous iteration).
+// k_mf_efused: reduction of the partials, eig of Gram(y3~_{n+1}) -> W_{n+1}, eig of Gram(B*L_n) -> feasibility,
+// history rows n (primal and dual complete), F* part of row n+1, mean for the next pass, stop rule for i = n.
+#pragma once
+#include "cp_mfnn_small.cuh"
+
+// u_n = (u_{n-1} - tau*(A'y_n)_u) - mean  and  u_{n-1} at position (i, jg) (element offset e) of image k;
+// w = -(A'y_n)_u is returned for the G* monitors.
+// All loads are unconditional (every field has a halo column on both sides, so e-1, e+1, e-m, e+m are always inside
+// the allocation); boundary handling happens in the arithmetic. This keeps the whole per-image body one basic block, so
+// the compiler can issue every load of the three positions before the first wait.
+template <bool LINEAR>
+__device__ __forceinline__ void primal_u_at(const MfParams &P, int k, int i, int jg, int e,
+                                            const double *__restrict__ xo, const double *__restrict__ p,
+                                            const double *__restrict__ g, double cnx, double cny,
+                                            double &uxn, double &uyn, double &uxo, double &uyo, double &wx, double &wy) {
+    const int K = P.K, m = P.m, fs = P.fs;
+    const double y1 = p[(size_t)k * fs + e];
+    const double gx = g[(size_t)(2 * k) * fs + e], gy = g[(size_t)(2 * k + 1) * fs + e];
+    const double *y2 = p + (size_t)(K + 4 * k) * fs + e;
+    double adj[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double *f = y2 + (size_t)c * fs;
+        const double wc = f[0];
+        if ((c & 1) == 0) {   // Dx component: adjoint along i
+            const double wraw = f[-1];
+            const double wm = (i >= 1) ? wraw : 0.0;
+            const double wl = LINEAR ? f[(m - 1) - i] : 0.0;
+            adj[c] = fwd_diff_adj(wc, wm, wl, i, m, LINEAR, P.inv_h1);
+        } else {              // Dy component: adjoint along j
+            const double wraw = f[-m];
+            const double wm = (jg >= 1) ? wraw : 0.0;
+            double wl = 0.0;
+            if (LINEAR) {
+                const int dj = (jg >= P.n_global - 2) ? (P.n_global - 1) - jg : 0;
+                wl = f[(size_t)dj * m];
+            }
+            adj[c] = fwd_diff_adj(wc, wm, wl, jg, P.n_global, LINEAR, P.inv_h2);
+        }
+    }
+    const double vux = -gx * y1 + (adj[0] + adj[1]);
+    const double vuy = -gy * y1 + (adj[2] + adj[3]);
+    uxo = xo[(size_t)(2 * k) * fs + e];
+    uyo = xo[(size_t)(2 * k + 1) * fs + e];
+    uxn = (uxo - P.tau * vux) - cnx;          // NNE/mean_zero_indicator.m:50
+    uyn = (uyo - P.tau * vuy) - cny;          // :53
+    wx = -vux;
+    wy = -vuy;
+}
+
+template <bool LINEAR, bool FULLK>
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_fused_tv(MfParams P, const double *__restrict__ xo,
+                                                          double *__restrict__ xn, const double *__restrict__ pin,
+                                                          double *__restrict__ pout, const double *__restrict__ g,
+                                                          const double *__restrict__ b, const double *__restrict__ W,
+                                                          const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
+    __shared__ double tiles[CP_WAVES * 2 * 16 * CP_TS];
+    __shared__ double red[CP_WAVES * CP_NSCAL];
+    __shared__ double Wl[CP_KMAX * CP_KMAX];
+    if (ctrl->stop) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *tileA = tiles + wave * 2 * 16 * CP_TS, *tileB = tileA + 16 * CP_TS;
+    const int K = P.K, m = P.m, fs = P.fs;
+    const bool linear = LINEAR;
+    stage_W(W, Wl);
+    __syncthreads();
+    const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
+    const double sigma = P.sigma, tau = P.tau, theta = P.theta, inv_sigma = 1.0 / P.sigma;
+    const double *y3in = pin + (size_t)(5 * K) * fs;
+    double *y3out = pout + (size_t)(5 * K) * fs;
+
+    double sums[CP_NSUM], maxs[CP_NMAX];
+#pragma unroll
+    for (int a = 0; a < CP_NSUM; ++a) sums[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < CP_NMAX; ++a) maxs[a] = -1.0e300;
+    maxs[DM_Y1 - CP_NSUM] = 0.0; maxs[DM_S1 - CP_NSUM] = 0.0; maxs[PM_VL - CP_NSUM] = 0.0;
+    double4_t acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+
+    // 1-D decomposition into chunks of 256 consecutive pixels (column-major): measured faster than 64 x 4 tiles
+    // (12.9 vs 14.1 ms at 4096^2 x 16), the j+-1 neighbour loads are served by L2 / Infinity Cache
+    for (int base = blockIdx.x * CP_BLOCK; base < P.npix; base += gridDim.x * CP_BLOCK) {
+        const bool valid = (base + tid) < P.npix;
+        const int q = valid ? base + tid : P.npix - 1;   // lanes past the end redo the last pixel, nothing is stored
+        const int j = q / m, i = q - j * m;
+        const int e = q + m;
+        const int jg = P.j_off + j;
+        const bool last_i = (i == m - 1), last_j = (jg == P.n_global - 1);
+
+        // ---- phase 1: everything that couples the K images of this pixel --------------------------------
+        // all 3K loads are issued up front (image index clamped for K < 16; FULLK folds the guards away)
+        double a[CP_KMAX], Lr[CP_KMAX], y1v[CP_KMAX];
+        {
+            double t3[CP_KMAX];
+#pragma unroll
+            for (int k = 0; k < CP_KMAX; ++k) {
+                const int kk = (FULLK || k < K) ? k : K - 1;
+                t3[k] = y3in[(size_t)kk * fs + e];
+                y1v[k] = pin[(size_t)kk * fs + e];
+                Lr[k] = xo[(size_t)(2 * K + kk) * fs + e];
+            }
+#pragma unroll
+            for (int kp = 0; kp < CP_KMAX; ++kp) a[kp] = 0.0;
+#pragma unroll
+            for (int k = 0; k < CP_KMAX; ++k) {
+                const double t = (FULLK || k < K) ? t3[k] : 0.0;
+#pragma unroll
+                for (int kp = 0; kp < CP_KMAX; ++kp) a[kp] = fma(t, Wl[k * CP_KMAX + kp], a[kp]);   // y3_n = y3~_n * W_n
+            }
+        }
+        double s3 = 0.0;
+#pragma unroll
+        for (int kp = 0; kp < CP_KMAX; ++kp) s3 += a[kp];
+        const double mean3 = s3 * P.invK;
+        double sumL = 0.0, sumLb = 0.0, vLmax = 0.0;
+#pragma unroll
+        for (int k = 0; k < CP_KMAX; ++k) {
+            const bool act = FULLK || (k < K);
+            const double Lo = Lr[k];
+            const double vL = y1v[k] + (a[k] - mean3);               // (A'y)_L = y1 + B*y3
+            const double Ln = Lo - tau * vL;                          // zero_function prox = identity
+            const double Lb = Ln + theta * (Ln - Lo);                 // chambolle_pock.m:179
+            vLmax = fmax(vLmax, act ? fabs(vL) : 0.0);                // NNE/zero_function.m:32
+            Lr[k] = act ? Ln : 0.0;
+            a[k] = a[k] + sigma * Lb;                                 // y3_n + sigma*Lbar (mean removed below)
+            sumL += act ? Ln : 0.0;
+            sumLb += act ? Lb : 0.0;
+            tileB[k * CP_TS + lane] = Lb;
+        }
+        if (valid) maxs[PM_VL - CP_NSUM] = fmax(maxs[PM_VL - CP_NSUM], vLmax);
+        const double smb = sigma * (sumLb * P.invK), mL = sumL * P.invK;
+#pragma unroll
+        for (int k = 0; k < CP_KMAX; ++k) {
+            const bool act = FULLK || (k < K);
+            const double v = (valid && act) ? a[k] - smb : 0.0;       // y3~_{n+1} = y3_n + sigma*B*Lbar
+            tileA[k * CP_TS + lane] = v;
+            if (valid && act) {
+                y3out[(size_t)k * fs + e] = v;
+                xn[(size_t)(2 * K + k) * fs + e] = Lr[k];
+            }
+        }
+        __syncthreads();
+        gram_tile_accum(tileA, acc1);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CP_KMAX; ++k)
+            tileA[k * CP_TS + lane] = (valid && (FULLK || k < K)) ? Lr[k] - mL : 0.0;   // B*L_n
+        __syncthreads();
+        gram_tile_accum(tileA, acc2);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CP_KMAX; ++k) tileA[k * CP_TS + lane] = Lr[k];
+
+        // ---- phase 2: per image: displacement part of the primal step (own pixel + 2 neighbours), dual step ----
+        const int oi = (last_i && LINEAR) ? -1 : 1, oj = (last_j && LINEAR) ? -1 : 1;
+        const double vmask = valid ? 1.0 : 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
+            double ux, uy, uxo_, uyo_, wx, wy, uxi, uyi, oi0, oi1, uxj, uyj, oj0, oj1, wd0, wd1;
+            primal_u_at<LINEAR>(P, k, i, jg, e, xo, pin, g, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
+            // neighbours along i and j ("previous" instead of "next" on a linear boundary row; unused otherwise)
+            primal_u_at<LINEAR>(P, k, i + oi, jg, e + oi, xo, pin, g, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
+            primal_u_at<LINEAR>(P, k, i, jg + oj, e + oj * m, xo, pin, g, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
+            const double gx = g[(size_t)(2 * k) * fs + e], gy = g[(size_t)(2 * k + 1) * fs + e];
+            const double bb = b[(size_t)k * fs + e];
+            const double y1 = pin[(size_t)k * fs + e];
+            const double *y2 = pin + (size_t)(K + 4 * k) * fs + e;
+            const double v0 = y2[0], v1 = y2[(size_t)fs], v2 = y2[2 * (size_t)fs], v3 = y2[3 * (size_t)fs];
+
+            if (valid) {
+                xn[(size_t)(2 * k) * fs + e] = ux;
+                xn[(size_t)(2 * k + 1) * fs + e] = uy;
+                // G*(-A'y_n): NNE/mean_zero_indicator.m:78-84
+                maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], wx);
+                maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], -wx);
+                maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], wy);
+                maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], -wy);
+            }
+            sums[PS_WX] += vmask * wx;
+            const double uxb = ux + theta * (ux - uxo_), uyb = uy + theta * (uy - uyo_);
+            const double uxbi = uxi + theta * (uxi - oi0), uybi = uyi + theta * (uyi - oi1);
+            const double uxbj = uxj + theta * (uxj - oj0), uybj = uyj + theta * (uyj - oj1);
+
+            // ---- y1: SAD* (identical to k_mf_dual) -------------------------------------------------
+            const double r_cur = -(gx * ux + gy * uy) + Lc;
+            const double r_bar = -(gx * uxb + gy * uyb) + Lbar;
+            sums[DS_F1] += vmask * fabs(r_cur - bb);                           // NNE/SAD.m:54
+            const double yt = y1 + sigma * r_bar;
+            const double Ls = yt * inv_sigma, thr = inv_sigma * P.mu1, dd = Ls - bb;
+            const double prox = (dd > thr) ? (Ls - thr) : ((dd < -thr) ? (Ls + thr) : bb);   // :42-49
+            const double y1n = yt - sigma * prox;                              // :71-72
+            sums[DS_F1S] += vmask * (y1n * bb);                                // :83
+            sums[DS_SGX] += vmask * (gx * y1n);
+            sums[DS_SGY] += vmask * (gy * y1n);
+
+            // ---- y2: pointwise 2x2 nuclear norm* ------------------------------------------------------
+            const double d0 = fwd_diff(ux, uxi, uxi, last_i, linear, P.inv_h1);
+            const double d1 = fwd_diff(ux, uxj, uxj, last_j, linear, P.inv_h2);
+            const double d2 = fwd_diff(uy, uyi, uyi, last_i, linear, P.inv_h1);
+            const double d3 = fwd_diff(uy, uyj, uyj, last_j, linear, P.inv_h2);
+            const double e0 = fwd_diff(uxb, uxbi, uxbi, last_i, linear, P.inv_h1);
+            const double e1 = fwd_diff(uxb, uxbj, uxbj, last_j, linear, P.inv_h2);
+            const double e2 = fwd_diff(uyb, uybi, uybi, last_i, linear, P.inv_h1);
+            const double e3 = fwd_diff(uyb, uybj, uybj, last_j, linear, P.inv_h2);
+            double s1v, s2v;
+            sv_2x2(d0, d1, d2, d3, s1v, s2v);
+            sums[DS_F2] += vmask * (s1v + s2v);                                // NNE/pointwise_2x2_nn.m:32
+            const double t0 = v0 + sigma * e0, t1 = v1 + sigma * e1, t2 = v2 + sigma * e2, t3 = v3 + sigma * e3;
+            double r0, r1, r2, r3;
+            svt_2x2(t0 * inv_sigma, t1 * inv_sigma, t2 * inv_sigma, t3 * inv_sigma, P.mu2 * inv_sigma, r0, r1, r2,
+                    r3);                                                       // :46-48
+            const double n0 = t0 - sigma * r0, n1 = t1 - sigma * r1, n2 = t2 - sigma * r2, n3 = t3 - sigma * r3;
+            sv_2x2(n0, n1, n2, n3, s1v, s2v);
+            if (valid) {
+                pout[(size_t)k * fs + e] = y1n;
+                double *o2 = pout + (size_t)(K + 4 * k) * fs + e;
+                o2[0] = n0; o2[(size_t)fs] = n1; o2[2 * (size_t)fs] = n2; o2[3 * (size_t)fs] = n3;
+                maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], fabs(y1n));
+                maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], s1v);      // :56
+            }
+            sums[DS_UX] += vmask * ux;
+            sums[DS_UY] += vmask * uy;
+        }
+    }
+    double *out = part + (size_t)blockIdx.x * CP_PSTRIDE;
+    block_reduce_store<CP_NSUM, CP_NMAX>(sums, maxs, red, out);
+    gram_block_store(acc1, tiles, out + CP_NSCAL);
+    gram_block_store(acc2, tiles, out + CP_NSCAL + 256);
+}
+
+struct EFusedArgs {
+    int nblk, K;
+    int n;               // iteration: completes primal row n and dual row n, starts dual row n+1
+    int check_stop;
+    double tol, mu1, mu2, sigma, tau, Ntot;
+};
+
+__global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, const double *__restrict__ part,
+                                                              CpCtrl *ctrl, double *__restrict__ Wout, double *hist_p,
+                                                              double *hist_d) {
+    __shared__ double G[16][17], V[16][17], G2[16][17], sc[CP_NSCAL], cs[8][2], dvec[16], stage[CP_RED_THREADS];
+    __shared__ int pq[8][2], rotflag;
+    __shared__ double res[4];   // spmax, con3
+    if (ctrl->stop) return;
+    const int t = threadIdx.x;
+    reduce_partials(part + 256, A.nblk, G2, sc, stage);   // Gram(B*L_n)   (second Gram block)
+    reduce_partials(part, A.nblk, G, sc, stage);          // Gram(y3~_{n+1}) and the scalars
+    jacobi16<true>(G, V, cs, pq, &rotflag);
+    if (t == 0) {
+        const int K = A.K;
+        const double nu = ctrl->nu, mu_ = nu * A.sigma;   // NNE/nuclear_norm_constraint.m:72
+        double S[16], z[16], zs[16];
+        double sumz = 0.0;
+        for (int i = 0; i < K; ++i) {
+            S[i] = sqrt(fmax(G[i][i], 0.0));
+            z[i] = S[i] / mu_;
+            zs[i] = z[i];
+            sumz += z[i];
+            ctrl->sv[i] = S[i];
+        }
+        double theta = 0.0;
+        const bool inside = (sumz <= 1.0);                // NNE/l1ball_projection.m:28
+        if (!inside) {
+            for (int i = 1; i < K; ++i) {
+                const double v = zs[i];
+                int j = i - 1;
+                while (j >= 0 && zs[j] < v) { zs[j + 1] = zs[j]; --j; }
+                zs[j + 1] = v;
+            }
+            double cum = 0.0;
+            for (int i = 0; i < K; ++i) {
+                cum += zs[i];
+                const double th = (cum - 1.0) / (double)(i + 1);
+                if (zs[i] - th > 0.0) theta = th;
+            }
+        }
+        double spmax = 0.0;
+        for (int i = 0; i < 16; ++i) dvec[i] = 0.0;
+        for (int i = 0; i < K; ++i) {
+            const double Pi = inside ? z[i] : fmax(z[i] - theta, 0.0);
+            const double sp = S[i] - mu_ * Pi;                            // :76
+            dvec[i] = (S[i] > 0.0) ? (mu_ * Pi) / S[i] : 0.0;
+            spmax = fmax(spmax, sp);
+        }
+        res[0] = spmax;
+    }
+    __syncthreads();
+    if (t < 256) {   // W_{n+1} = I - V diag(d) V'
+        const int k = t >> 4, kp = t & 15;
+        double a = (k == kp) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a -= V[k][i] * dvec[i] * V[kp][i];
+        Wout[k * CP_KMAX + kp] = a;
+    }
+    {   // Gram(B*L_n) restricted to the complement of (1,..,1) (see k_mf_fin), then eigenvalues
+        const int a = (t >> 4) & 15, bq = t & 15, K = A.K;
+        double acc = 0.0;
+        if (t < 256 && a < K - 1 && bq < K - 1) {
+            const double na = 1.0 / sqrt((double)(a + 1) * (a + 2)), nb = 1.0 / sqrt((double)(bq + 1) * (bq + 2));
+            for (int i = 0; i <= a + 1; ++i) {
+                const double qa = (i <= a) ? na : -(double)(a + 1) * na;
+                double row = 0.0;
+                for (int j = 0; j <= bq + 1; ++j) {
+                    const double qb = (j <= bq) ? nb : -(double)(bq + 1) * nb;
+                    row += G2[i][j] * qb;
+                }
+                acc += qa * row;
+            }
+        }
+        __syncthreads();
+        if (t < 256) G[a][bq] = acc;
+        __syncthreads();
+    }
+    jacobi16<false>(G, nullptr, cs, pq, &rotflag);
+    if (t == 0) {
+        const double nu = ctrl->nu;
+        double sumS = 0.0;
+        for (int i = 0; i < A.K; ++i) ctrl->svL[i] = 0.0;
+        for (int i = 0; i < A.K - 1; ++i) {
+            const double s = sqrt(fmax(G[i][i], 0.0));
+            ctrl->svL[i] = s;
+            sumS += s;
+        }
+        const int n = A.n;
+        double *hp = hist_p + (size_t)n * CP_HCOLS_MF;
+        double *hd = hist_d + (size_t)n * CP_HCOLS_MF, *hd1 = hist_d + (size_t)(n + 1) * CP_HCOLS_MF;
+        // primal row n                                        chambolle_pock.m:168-171
+        const double F1 = A.mu1 * sc[DS_F1], F2 = A.mu2 * sc[DS_F2];
+        hp[1] = F1; hp[2] = F2; hp[3] = 0.0; hp[4] = 0.0;
+        hp[0] = hp[4] + (F1 + F2 + 0.0);
+        hp[5] = (sumS > nu) ? (sumS - nu) / nu : 0.0;          // nuclear_norm_constraint.m:55-59
+        hp[6] = fmax(fabs(sc[DS_UX] / A.Ntot), fabs(sc[DS_UY] / A.Ntot));   // mean_zero_indicator.m:65
+        // dual row n: G* part (F* part was stored one iteration earlier)     :173-176
+        const double mw = sc[PS_WX] / A.Ntot;
+        const double dx = fmax(sc[PM_WXMAX] - mw, mw - (-sc[PM_WXMIN]));
+        const double dy = fmax(sc[PM_WYMAX] - mw, mw - (-sc[PM_WYMIN]));
+        hd[4] = 0.0;
+        hd[6] = fmax(fmax(dx, dy), sc[PM_VL]);
+        hd[0] = -(hd[4] + (hd[1] + hd[2] + hd[3]));
+        // dual row n+1: F* part of y_{n+1}
+        hd1[1] = sc[DS_F1S];
+        hd1[2] = 0.0;
+        hd1[3] = nu * res[0];
+        const double con1 = (sc[DM_Y1] > A.mu1) ? sc[DM_Y1] - A.mu1 : 0.0;
+        const double con2 = fmax((sc[DM_S1] - A.mu2) / A.mu2, 0.0);
+        hd1[5] = fmax(con1, con2);
+        // mean of the next un-projected u
+        ctrl->cn[0] = sc[DS_UX] / A.Ntot + A.tau * (sc[DS_SGX] / A.Ntot);
+        ctrl->cn[1] = sc[DS_UY] / A.Ntot + A.tau * (sc[DS_SGY] / A.Ntot);
+        if (A.check_stop && n >= 4) {                          // chambolle_pock.m:142-153
+            bool ok = true;
+            for (int r = n - 4; r <= n; ++r) {
+                const double *p_ = hist_p + (size_t)r * CP_HCOLS_MF, *d_ = hist_d + (size_t)r * CP_HCOLS_MF;
+                const double gap = fabs((p_[0] - d_[0]) / d_[0]);
+                if (!(gap <= A.tol) || !(p_[5] <= A.tol) || !(p_[6] <= A.tol) || !(d_[5] <= A.tol) || !(d_[6] <= A.tol))
+                    ok = false;
+            }
+            if (ok) { ctrl->stop = 1; ctrl->stop_iter = n; }
+        }
+    }
+}

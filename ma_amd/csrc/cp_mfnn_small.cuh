@@ -13,6 +13,8 @@ struct EigArgs {
     int update;          // fin: store the new mean offsets into ctrl->c[newbuf]
     int newbuf;
     int monitor;         // eig: the dual row describes y_in itself (row 0), not the projected y
+    int compute_cn;      // eig: store the mean of the next un-projected u into ctrl->cn (start of the fused passes)
+    double tau;
     double tol, mu1, mu2, sigma, Ntot;
 };
 
@@ -42,21 +44,22 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
     if (t < 256) G[t >> 4][t & 15] = (stage[t] + stage[256 + t]) + (stage[512 + t] + stage[768 + t]);
     __syncthreads();
     {
-        const int slot = t & 15, sub = t >> 4;   // 64 sub-groups
+        const int slot = t & 31, sub = t >> 5;   // 32 sub-groups of 32 threads (CP_NSCAL <= 32 slots used)
         const bool is_sum = slot < CP_NSUM;
         double v = is_sum ? 0.0 : -1.0e300;
-        for (int bI = sub; bI < nblk; bI += 64) {
-            const double o = part[(size_t)bI * CP_PSTRIDE + slot];
-            v = is_sum ? v + o : fmax(v, o);
-        }
+        if (slot < CP_NSCAL)
+            for (int bI = sub; bI < nblk; bI += 32) {
+                const double o = part[(size_t)bI * CP_PSTRIDE + slot];
+                v = is_sum ? v + o : fmax(v, o);
+            }
         stage[t] = v;
     }
     __syncthreads();
     if (t < CP_NSCAL) {
         const bool is_sum = t < CP_NSUM;
         double v = stage[t];
-        for (int sub = 1; sub < 64; ++sub) {
-            const double o = stage[sub * 16 + t];
+        for (int sub = 1; sub < 32; ++sub) {
+            const double o = stage[sub * 32 + t];
             v = is_sum ? v + o : fmax(v, o);
         }
         sc[t] = v;
@@ -186,6 +189,11 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_eig(EigArgs A, const doub
             const double con1 = (sc[DM_Y1] > A.mu1) ? sc[DM_Y1] - A.mu1 : 0.0;     // NNE/SAD.m:77-81
             const double con2 = (A.reg == 0) ? fmax((sc[DM_S1] - A.mu2) / A.mu2, 0.0) : 0.0;
             hd[5] = fmax(fmax(con1, con2), 0.0);
+        }
+        if (A.compute_cn) {
+            // mean(u - tau*(A'y)_u) = mean(u) + tau*mean(grad T' y1): D'y2 has zero mean because D*1 = 0
+            ctrl->cn[0] = sc[DS_UX] / A.Ntot + A.tau * (sc[DS_SGX] / A.Ntot);
+            ctrl->cn[1] = sc[DS_UY] / A.Ntot + A.tau * (sc[DS_SGY] / A.Ntot);
         }
         if (A.rp >= 0) {
             double *hp = hist_p + (size_t)A.rp * CP_HCOLS_MF;

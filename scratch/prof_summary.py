@@ -9,14 +9,14 @@ for f in glob.glob(out + '/trace/**/*kernel_stats.csv', recursive=True):
     for r in rows[:14]:
         print(f"{short(r['Name']):70s} calls {r['Calls']:>6s} avg_ns {float(r['AverageNs']):>14.0f} total% {r['Percentage']}")
 # pmc
-for sub in ('pmc_sq', 'pmc_fetch', 'pmc_write'):
+for sub in ('pmc_sq', 'pmc_sq2', 'pmc_fetch', 'pmc_write'):
     for f in glob.glob(out + f'/{sub}/**/*counter_collection.csv', recursive=True):
         print('== pmc', sub)
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, d in agg.items():
-            if not (k.startswith('void k_mf_dual') or k.startswith('void k_mf_primal') or 'k_mf_eig' in k or 'k_mf_fin' in k):
+            if not ('k_mf_fused' in k or 'k_mf_efused' in k or 'k_pw_' in k):
                 continue
             # steady-state launches: take the median over dispatches
             s = ' '.join(f"{c}={sorted(v)[len(v)//2]:.4g}" for c, v in d.items())
