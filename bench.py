@@ -37,8 +37,8 @@ def parse():
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--reg", default="tv", choices=["tv", "curvature"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-size", type=int, default=192)
-    ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--cpu-size", type=int, default=512)
+    ap.add_argument("--cpu-iters", type=int, default=8)
     return ap.parse_args()
 
 
@@ -135,6 +135,15 @@ def main():
     times = solver.kernel_times()
 
     if rank == 0:
+        # HBM bytes per launch of the dominant kernel as measured by rocprofv3 PMC passes (profiles/, collected by
+        # scratch/prof.sh on the same workload); null when no matching measurement is committed
+        traffic = None
+        try:
+            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+            if prof and reg == "tv" and m == 4096 and k == 16 and world == 1:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))["hbm_bytes_per_launch"] / 1e9
+        except Exception:
+            traffic = None
         kmn_total = float(k) * m * n
         its = args.steps / dt
         bytes_iter = ELEMS_ITER[reg] * 8.0 * kmn_total
@@ -165,7 +174,8 @@ def main():
                        "frac_of_hbm_peak": bytes_iter * its / 1e9 / (HBM_PEAK_GBS * world),
                        "kernel_ms": {kname: (v[0] / max(v[1], 1)) for kname, v in times.items()}},
             "roofline": {"bound": "hbm", "kernel": DOM_KERNEL[reg], "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)"},
         }
         if not args.no_cpu_baseline:
             cits, cdt = cpu_baseline(args.cpu_size, k, args.cpu_iters, reg)
