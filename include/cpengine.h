@@ -158,6 +158,40 @@ int cp_iterate(cp_handle h, double theta, double tau, double sigma, int32_t iter
 int cp_sync(cp_handle h);
 int cp_kernel_time_ms(cp_handle h, const char *pass, double *ms, int64_t *launches);
 
+/* --- row-slab multi-GPU hooks (no counterpart in the reference; NN-TV model) -----------------------
+ * One process per GPU, each with a handle created with n = owned columns, n_global, j_offset. The
+ * library launches kernels and packs/unpacks halo columns; the CALLER moves the packed buffers and the
+ * reduced partials between ranks (RCCL through torch.distributed, see ma_amd/slab_mg.py). All device
+ * pointers passed in are caller-owned device memory; kernels run on the stream given to cp_set_stream
+ * (e.g. torch's current stream), so the caller's collectives on that stream are ordered with them.   */
+enum { CP_BUF_X0 = 0, CP_BUF_X1 = 1, CP_BUF_P0 = 2, CP_BUF_P1 = 3, CP_BUF_XTMP = 4 };
+enum { CP_SEL_ALL = 0, CP_SEL_X_U = 1, CP_SEL_P_Y12 = 2, CP_SEL_P_DY = 3 };
+enum { CP_STAGE_DUAL0 = 0,   /* dual step 1 alone (first kernel of a solve) + local reduction -> red      */
+       CP_STAGE_EIG0 = 1,    /* eigensolve on the gathered partials of DUAL0                               */
+       CP_STAGE_FUSED = 2,   /* k_mf_fused_tv for iteration n + local reduction -> red                     */
+       CP_STAGE_EFUSED = 3,  /* k_mf_efused for iteration n on the gathered partials                       */
+       CP_STAGE_APPLY_A = 4, /* power iteration: P1 = A * (scale * X1)                                     */
+       CP_STAGE_APPLY_AT = 5 /* power iteration: XTMP = A' * P1, local sum of squares -> red[0]; swaps X1/XTMP */ };
+int cp_set_stream(cp_handle h, void *hip_stream);          /* NULL = the handle's own stream            */
+int64_t cp_mg_partial_len(void);                           /* doubles per reduced partial vector        */
+int64_t cp_mg_halo_len(cp_handle h, int sel);              /* doubles per packed halo column            */
+/* column = 0: first owned column, 1: last owned column -> dev_out                                      */
+int cp_mg_halo_pack(cp_handle h, int buf, int sel, int column, double *dev_out);
+/* side = 0: left halo column, 1: right halo column <- dev_in                                           */
+int cp_mg_halo_unpack(cp_handle h, int buf, int sel, int side, const double *dev_in);
+int cp_mg_begin(cp_handle h, double theta, double tau, double sigma);
+/* dev_buf: stage output (own reduced partials) or input (world gathered partial vectors)               */
+int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, int32_t world, double scale,
+                int32_t check_stop, double tol);
+int cp_mg_end(cp_handle h, int32_t iterations);
+/* stop flag / iteration of the stop rule after the last EFUSED stage (synchronises)                    */
+int cp_mg_stop_state(cp_handle h, int32_t *stopped, int32_t *stop_iter);
+/* local Gram matrix (16x16, row-major, host) of (B*field)*V over the owned pixels; which as in
+ * cp_singular_values, V = 16x16 row-major host matrix or NULL for the identity                         */
+int cp_mg_gram(cp_handle h, int which, const double *V, double *gram);
+/* power iteration start: fills X1 with the deterministic start vector (global indices), zeroes XTMP    */
+int cp_mg_power_start(cp_handle h, double *local_sumsq);
+
 #ifdef __cplusplus
 }
 #endif

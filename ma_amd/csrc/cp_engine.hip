@@ -67,7 +67,10 @@ struct cp_engine {
     int nblk = 0;
     int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU: two LDS tiles per wave)
     bool linearized = false, has_nu = false, has_images = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless cp_set_stream)
+    hipStream_t own_stream = nullptr;
+    double mg_theta = 1.0, mg_tau = 0.0, mg_sigma = 0.0;
+    double *red = nullptr;             // reduced partial vector of this rank (CP_PSTRIDE doubles)
     std::vector<cp_result> last;   // per problem
     bool profile = false;
     PassTimer timers[T_COUNT];
@@ -166,6 +169,7 @@ extern "C" int cp_destroy(cp_handle h) {
     if (!h) return CP_OK;
     hipSetDevice(h->d.device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->red) hipFree(h->red);
     double *ptrs[] = {h->X[0], h->X[1], h->P[0], h->P[1], h->g, h->b, h->Tu, h->img, h->imgR, h->W[0], h->W[1],
                       h->W[2], h->xtmp, h->part, h->part2, h->svout, h->hist_p, h->hist_d};
     for (double *p : ptrs)
@@ -173,7 +177,7 @@ extern "C" int cp_destroy(cp_handle h) {
     if (h->ctrl) hipFree(h->ctrl);
     for (auto &t : h->timers)
         for (hipEvent_t e : t.ev) hipEventDestroy(e);
-    if (h->stream) hipStreamDestroy(h->stream);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return CP_OK;
 }
@@ -193,6 +197,12 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");   // finite_difference_operator.m:35
         if (d.bc < 0 || d.bc > 2) CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");
         if (d.batch > 1) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported batch > 1 for mf_nn models");
+        if (d.n_global > 0 && d.n_global != d.n) {
+            if (d.model != CP_MODEL_MF_NN_TV || d.bc != CP_BC_NEUMANN)
+                CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported row slabs need the NN-TV model with neumann boundary");
+            if (d.j_offset < 0 || d.j_offset + d.n > d.n_global)
+                CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg slab [%d, %d) outside [0, %d)", d.j_offset, d.j_offset + d.n, d.n_global);
+        }
     }
     cp_engine *h = new cp_engine();
     h->d = d;
@@ -225,7 +235,8 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
     int rc = CP_OK;
     auto body = [&]() -> int {
         HIPCHK(hipSetDevice(d.device));
-        HIPCHK(hipStreamCreate(&h->stream));
+        HIPCHK(hipStreamCreate(&h->own_stream));
+        h->stream = h->own_stream;
         h->xN = (size_t)h->nxf * h->fs * h->batch;
         h->pN = (size_t)h->npf * h->fs * h->batch;
         for (int a = 0; a < 2; ++a) {
@@ -251,6 +262,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
             HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(h->nblk, h->nblk_fused) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->svout, sizeof(double) * (16 + 256 + 256)));
+            HIPCHK(hipMalloc(&h->red, sizeof(double) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->ctrl, sizeof(CpCtrl)));
             HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(CpCtrl), h->stream));
             hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1]);
@@ -344,7 +356,12 @@ extern "C" int cp_linearize(cp_handle h, const double *u0) {
         W.hx = (h->d.omega[1] - h->d.omega[0]) / h->m;              // IRE/cell_centered_grid.m:21-22
         W.hy = (h->d.omega[3] - h->d.omega[2]) / h->d.n_global;
         W.inv_h1 = 1.0 / h->d.h[0]; W.inv_h2 = 1.0 / h->d.h[1];
-        const long long tot = (long long)h->npix * h->K;
+        // slabs: also linearise the halo columns that lie inside the image (the fused pass recomputes the primal
+        // update at j+1); the caller has exchanged the halo columns of u before
+        W.jlo = (h->d.j_offset > 0) ? -1 : 0;
+        const int jhi = (h->d.j_offset + h->nl < h->d.n_global) ? h->nl : h->nl - 1;
+        W.npix = h->m * (jhi - W.jlo + 1);
+        const long long tot = (long long)W.npix * h->K;
         const int grid = (int)((tot + CP_BLOCK - 1) / CP_BLOCK);
         hipLaunchKernelGGL(k_mf_warp, dim3(grid), dim3(CP_BLOCK), 0, h->stream, W, h->img, xsrc, h->Tu, h->g, h->b);
     } else {
@@ -927,5 +944,229 @@ extern "C" int cp_kernel_time_ms(cp_handle h, const char *pass, double *ms, int6
     *ms = tot;
     if (launches) *launches = (int64_t)(t.used / 2);
     t.used = 0;
+    return CP_OK;
+}
+
+// ================================================================================================
+// row-slab multi-GPU hooks
+__global__ __launch_bounds__(CP_RED_THREADS) void k_mf_reduce_local(int nblk, const double *__restrict__ part,
+                                                                    double *__restrict__ out) {
+    __shared__ double G[16][17], G2[16][17], sc[CP_NSCAL], stage[CP_RED_THREADS];
+    const int t = threadIdx.x;
+    reduce_partials(part + 256, nblk, G2, sc, stage);
+    reduce_partials(part, nblk, G, sc, stage);
+    if (t < CP_NSCAL) out[t] = sc[t];
+    if (t < 256) {
+        out[CP_NSCAL + t] = G[t >> 4][t & 15];
+        out[CP_NSCAL + 256 + t] = G2[t >> 4][t & 15];
+    }
+}
+
+__global__ __launch_bounds__(CP_BLOCK) void k_halo_copy(int m, int fs, int nsel, int sel, int K, int col, int pack,
+                                                        double *__restrict__ buf, double *__restrict__ lin) {
+    const int tot = nsel * m;
+    for (int gid = blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot; gid += gridDim.x * CP_BLOCK) {
+        const int s = gid / m, i = gid - s * m;
+        int f = s;                                                  // CP_SEL_ALL, CP_SEL_X_U, CP_SEL_P_Y12: leading fields
+        if (sel == CP_SEL_P_DY) f = K + 4 * (s >> 1) + 1 + 2 * (s & 1);   // Dy u_x, Dy u_y of image s/2
+        double *p = buf + (size_t)f * fs + (size_t)col * m + i;
+        if (pack) lin[gid] = *p; else *p = lin[gid];
+    }
+}
+
+__global__ __launch_bounds__(CP_BLOCK) void k_sumsq_fields(int npix, int m, int fs, int nfields, const double *__restrict__ x,
+                                                           double *__restrict__ part) {
+    __shared__ double red[CP_WAVES * 2];
+    double ss[1] = {0.0}, mm[1] = {0.0};
+    const long long tot = (long long)npix * nfields;
+    for (long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot; gid += (long long)gridDim.x * CP_BLOCK) {
+        const int f = (int)(gid / npix), q = (int)(gid - (long long)f * npix);
+        const double v = x[(size_t)f * fs + m + q];
+        ss[0] += v * v;
+    }
+    block_reduce_store<1, 1>(ss, mm, red, part + (size_t)blockIdx.x * CP_PSTRIDE);
+}
+
+static int mg_nsel(const cp_engine *h, int buf, int sel) {
+    const bool isx = (buf == CP_BUF_X0 || buf == CP_BUF_X1 || buf == CP_BUF_XTMP);
+    switch (sel) {
+        case CP_SEL_ALL: return isx ? h->nxf : h->npf;
+        case CP_SEL_X_U: return isx ? 2 * h->K : -1;
+        case CP_SEL_P_Y12: return isx ? -1 : 5 * h->K;
+        case CP_SEL_P_DY: return isx ? -1 : 2 * h->K;
+    }
+    return -1;
+}
+static double *mg_buf(cp_engine *h, int buf) {
+    switch (buf) {
+        case CP_BUF_X0: return h->X[0];
+        case CP_BUF_X1: return h->X[1];
+        case CP_BUF_P0: return h->P[0];
+        case CP_BUF_P1: return h->P[1];
+        case CP_BUF_XTMP: return h->xtmp;
+    }
+    return nullptr;
+}
+
+extern "C" int cp_set_stream(cp_handle h, void *hip_stream) {
+    if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return CP_OK;
+}
+extern "C" int64_t cp_mg_partial_len(void) { return CP_PSTRIDE; }
+extern "C" int64_t cp_mg_halo_len(cp_handle h, int sel) {
+    if (!h || !h->mf) return -1;
+    const int n = (sel == CP_SEL_ALL) ? std::max(h->nxf, h->npf) : mg_nsel(h, sel == CP_SEL_X_U ? CP_BUF_X0 : CP_BUF_P0, sel);
+    return n < 0 ? -1 : (int64_t)n * h->m;
+}
+static int mg_halo(cp_handle h, int buf, int sel, int col, int pack, double *lin) {
+    if (!h || !h->mf || !lin) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg halo exchange needs an mf_nn handle and a buffer");
+    HIPCHK(hipSetDevice(h->d.device));
+    double *b = mg_buf(h, buf);
+    const int nsel = mg_nsel(h, buf, sel);
+    if (!b || nsel <= 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg halo buffer %d / selection %d", buf, sel);
+    const int grid = std::max(1, std::min((nsel * h->m + CP_BLOCK - 1) / CP_BLOCK, 1024));
+    hipLaunchKernelGGL(k_halo_copy, dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->fs, nsel, sel, h->K, col, pack, b, lin);
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+extern "C" int cp_mg_halo_pack(cp_handle h, int buf, int sel, int column, double *dev_out) {
+    return mg_halo(h, buf, sel, column ? (h ? h->nl : 0) : 1, 1, dev_out);          // owned columns are 1..nl
+}
+extern "C" int cp_mg_halo_unpack(cp_handle h, int buf, int sel, int side, const double *dev_in) {
+    return mg_halo(h, buf, sel, side ? (h ? h->nl + 1 : 0) : 0, 0, (double *)dev_in);   // halo columns 0 and nl+1
+}
+
+extern "C" int cp_mg_begin(cp_handle h, double theta, double tau, double sigma) {
+    if (!h || !h->mf || h->reg != 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_begin needs an NN-TV handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    if (!h->linearized || !h->has_nu) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_begin before linearize / set_nu");
+    h->mg_theta = theta; h->mg_tau = tau; h->mg_sigma = sigma;
+    CPCHK(ensure_hist(h, 4096));
+    h->profile = true;     // per-launch HIP events of the fused kernel (cp_kernel_time_ms)
+    return mf_begin(h);
+}
+
+extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, int32_t world, double scale,
+                           int32_t check_stop, double tol) {
+    if (!h || !h->mf || h->reg != 0 || !dev_buf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_stage");
+    HIPCHK(hipSetDevice(h->d.device));
+    const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
+    CpCtrl *ctrl = (CpCtrl *)h->ctrl;
+    switch (stage) {
+        case CP_STAGE_DUAL0:
+            launch_mf_dual<0>(h, P, h->X[0], h->X[1], h->P[0], h->P[1], h->W[0], 0, 1);
+            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk, h->part, dev_buf);
+            break;
+        case CP_STAGE_EIG0: {
+            EigArgs A = eig_args(h, P, -1, 1, 0, 0, 0, tol, 0, 1);
+            A.nblk = world;
+            hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->W[1], h->hist_p,
+                               h->hist_d);
+            break;
+        }
+        case CP_STAGE_FUSED: {
+            if (n + 2 > h->hist_rows) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg iteration %d beyond the history capacity", n);
+            const int cur = n & 1, prv = (n - 1) & 1, nxt = (n + 1) & 1;
+            CPCHK(timer_begin(h, T_DUAL));
+            auto kern = (h->K == CP_KMAX) ? k_mf_fused_tv<false, true> : k_mf_fused_tv<false, false>;
+            hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, h->X[prv], h->X[cur], h->P[cur],
+                               h->P[nxt], h->g, h->b, h->W[cur], (const CpCtrl *)ctrl, h->part);
+            CPCHK(timer_end(h, T_DUAL));
+            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk_fused, h->part, dev_buf);
+            break;
+        }
+        case CP_STAGE_EFUSED: {
+            EFusedArgs A;
+            A.nblk = world; A.K = h->K; A.n = n; A.check_stop = check_stop; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
+            A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot;
+            CPCHK(timer_begin(h, T_EIG));
+            hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->W[(n + 1) & 1],
+                               h->hist_p, h->hist_d);
+            CPCHK(timer_end(h, T_EIG));
+            break;
+        }
+        case CP_STAGE_APPLY_A:
+            hipLaunchKernelGGL((k_mf_applyA<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[1], scale, h->g, h->P[1]);
+            break;
+        case CP_STAGE_APPLY_AT:
+            hipLaunchKernelGGL((k_mf_applyAT<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->P[1], h->g, h->xtmp, h->part);
+            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk, h->part, dev_buf);
+            std::swap(h->X[1], h->xtmp);
+            break;
+        default:
+            CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg unknown stage %d", stage);
+    }
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+
+extern "C" int cp_mg_end(cp_handle h, int32_t iterations) {
+    if (!h || !h->mf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_end");
+    HIPCHK(hipSetDevice(h->d.device));
+    const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
+    int zero = 0;
+    HIPCHK(hipMemcpyAsync(h->ctrl, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    CPCHK(mf_end(h, P, iterations));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->profile = false;
+    h->last[0] = cp_result{iterations, CP_STOP_MAXITER, iterations + 1, h->hcols};
+    return CP_OK;
+}
+
+extern "C" int cp_mg_stop_state(cp_handle h, int32_t *stopped, int32_t *stop_iter) {
+    if (!h || !h->mf || !stopped || !stop_iter) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_stop_state");
+    HIPCHK(hipSetDevice(h->d.device));
+    int hdr[2];
+    HIPCHK(hipMemcpyAsync(hdr, h->ctrl, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *stopped = hdr[0];
+    *stop_iter = hdr[1];
+    return CP_OK;
+}
+
+extern "C" int cp_mg_gram(cp_handle h, int which, const double *V, double *gram) {
+    if (!h || !h->mf || !gram) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_gram");
+    HIPCHK(hipSetDevice(h->d.device));
+    const double *field = (which == 0) ? h->Tu : h->X[0] + (size_t)2 * h->K * h->fs;
+    if (which == 0 && !h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_gram(0) before cp_linearize");
+    MfParams P = mf_params(h, 1.0, 1.0, 1.0);
+    double *ident = h->svout + 16 + 256, *Vd = ident;
+    if (V) {
+        HIPCHK(hipMemcpyAsync(h->W[2], V, sizeof(double) * 256, hipMemcpyHostToDevice, h->stream));
+        Vd = h->W[2];
+    }
+    hipLaunchKernelGGL(k_mf_gram_field, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, field, Vd, h->part);
+    // only the first Gram block of the partials is written by k_mf_gram_field: clear the rest first
+    HIPCHK(hipGetLastError());
+    std::vector<double> hp((size_t)h->nblk * CP_PSTRIDE);
+    HIPCHK(hipMemcpyAsync(hp.data(), h->part, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int e = 0; e < 256; ++e) {
+        double s = 0.0;
+        for (int bI = 0; bI < h->nblk; ++bI) s += hp[(size_t)bI * CP_PSTRIDE + CP_NSCAL + e];
+        gram[e] = s;
+    }
+    return CP_OK;
+}
+
+extern "C" int cp_mg_power_start(cp_handle h, double *local_sumsq) {
+    if (!h || !h->mf || !local_sumsq) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_power_start");
+    HIPCHK(hipSetDevice(h->d.device));
+    MfParams P = mf_params(h, 1.0, 1.0, 1.0);
+    HIPCHK(hipMemsetAsync(h->X[1], 0, sizeof(double) * h->xN, h->stream));
+    HIPCHK(hipMemsetAsync(h->xtmp, 0, sizeof(double) * h->xN, h->stream));
+    hipLaunchKernelGGL(k_mf_hash_start, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[1]);
+    hipLaunchKernelGGL(k_sumsq_fields, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, h->npix, h->m, h->fs, h->nxf, h->X[1],
+                       h->part);
+    HIPCHK(hipGetLastError());
+    std::vector<double> hp((size_t)h->nblk * CP_PSTRIDE);
+    HIPCHK(hipMemcpyAsync(hp.data(), h->part, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double s = 0.0;
+    for (int bI = 0; bI < h->nblk; ++bI) s += hp[(size_t)bI * CP_PSTRIDE];
+    *local_sumsq = s;
     return CP_OK;
 }

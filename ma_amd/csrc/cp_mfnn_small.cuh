@@ -332,6 +332,7 @@ __global__ void k_mf_reset_ctrl(CpCtrl *ctrl, double *W0, double *W1) {
 // logic -- is bit-identical to the CPU restatement.
 struct WarpParams {
     int m, nl, K, npix, n_global, j_off, fs;
+    int jlo;                 // first local column processed (-1: the left halo column), npix = m * number of columns
     int mi, ni;              // image size (rows, cols) -- equals (m, n_global) in the drivers
     int ifs;                 // image field stride (mi*ni)
     double om0, om2, hx, hy; // grid origin and cell size
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_warp(WarpParams P, const double
     const long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x;
     if (gid >= (long long)P.npix * P.K) return;
     const int k = (int)(gid / P.npix), q = (int)(gid - (long long)k * P.npix);
-    const int j = q / P.m, i = q - j * P.m, e = q + P.m;
+    const int jj = q / P.m, i = q - jj * P.m, j = jj + P.jlo, e = (j + 1) * P.m + i;
     const double ux = x[(size_t)(2 * k) * P.fs + e], uy = x[(size_t)(2 * k + 1) * P.fs + e];
     const double px = __dadd_rn(__dadd_rn(P.om0, __dmul_rn(P.hx, (double)i + 0.5)), ux);
     const double py = __dadd_rn(__dadd_rn(P.om2, __dmul_rn(P.hy, (double)(P.j_off + j) + 0.5)), uy);

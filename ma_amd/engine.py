@@ -66,11 +66,24 @@ def _load():
         "cp_iterate": [vp, C.c_double, C.c_double, C.c_double, C.c_int32],
         "cp_sync": [vp],
         "cp_kernel_time_ms": [vp, C.c_char_p, dp, C.POINTER(C.c_int64)],
+        "cp_set_stream": [vp, vp],
+        "cp_mg_halo_pack": [vp, C.c_int, C.c_int, C.c_int, vp],
+        "cp_mg_halo_unpack": [vp, C.c_int, C.c_int, C.c_int, vp],
+        "cp_mg_begin": [vp, C.c_double, C.c_double, C.c_double],
+        "cp_mg_stage": [vp, C.c_int, C.c_int32, vp, C.c_int32, C.c_double, C.c_int32, C.c_double],
+        "cp_mg_end": [vp, C.c_int32],
+        "cp_mg_stop_state": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+        "cp_mg_gram": [vp, C.c_int, dp, dp],
+        "cp_mg_power_start": [vp, dp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.cp_mg_partial_len.argtypes = []
+    lib.cp_mg_partial_len.restype = C.c_int64
+    lib.cp_mg_halo_len.argtypes = [vp, C.c_int]
+    lib.cp_mg_halo_len.restype = C.c_int64
     return lib
 
 
@@ -78,7 +91,13 @@ lib = _load()
 EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_images", "cp_set_primal", "cp_set_dual",
             "cp_linearize", "cp_get_linearization", "cp_set_nu", "cp_singular_values", "cp_norm_estimate", "cp_solve",
             "cp_get_result", "cp_get_history", "cp_get_primal", "cp_get_dual", "cp_get_images", "cp_prolong",
-            "cp_downsample", "cp_iterate", "cp_sync", "cp_kernel_time_ms"]
+            "cp_downsample", "cp_iterate", "cp_sync", "cp_kernel_time_ms", "cp_set_stream", "cp_mg_partial_len",
+            "cp_mg_halo_len", "cp_mg_halo_pack", "cp_mg_halo_unpack", "cp_mg_begin", "cp_mg_stage", "cp_mg_end",
+            "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start"]
+
+BUF_X0, BUF_X1, BUF_P0, BUF_P1, BUF_XTMP = 0, 1, 2, 3, 4
+SEL_ALL, SEL_X_U, SEL_P_Y12, SEL_P_DY = 0, 1, 2, 3
+STAGE_DUAL0, STAGE_EIG0, STAGE_FUSED, STAGE_EFUSED, STAGE_APPLY_A, STAGE_APPLY_AT = 0, 1, 2, 3, 4, 5
 
 
 def _chk(rc):
@@ -225,6 +244,44 @@ class Engine:
 
     def downsample_to(self, coarse):
         _chk(lib.cp_downsample(self._h, coarse._h))
+
+    # row-slab multi-GPU hooks (device pointers are plain ints, e.g. torch.Tensor.data_ptr())
+    def set_stream(self, stream_ptr):
+        _chk(lib.cp_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def halo_len(self, sel):
+        return int(lib.cp_mg_halo_len(self._h, sel))
+
+    def halo_pack(self, buf, sel, column, dev_ptr):
+        _chk(lib.cp_mg_halo_pack(self._h, buf, sel, column, C.c_void_p(dev_ptr)))
+
+    def halo_unpack(self, buf, sel, side, dev_ptr):
+        _chk(lib.cp_mg_halo_unpack(self._h, buf, sel, side, C.c_void_p(dev_ptr)))
+
+    def mg_begin(self, theta, tau, sigma):
+        _chk(lib.cp_mg_begin(self._h, theta, tau, sigma))
+
+    def mg_stage(self, stage, n, dev_ptr, world=1, scale=1.0, check_stop=0, tol=0.0):
+        _chk(lib.cp_mg_stage(self._h, stage, n, C.c_void_p(dev_ptr), world, scale, check_stop, tol))
+
+    def mg_end(self, iterations):
+        _chk(lib.cp_mg_end(self._h, iterations))
+
+    def mg_stop_state(self):
+        a, b = C.c_int32(), C.c_int32()
+        _chk(lib.cp_mg_stop_state(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def mg_gram(self, which, V=None):
+        V = None if V is None else np.ascontiguousarray(V, dtype=np.float64)
+        g = np.empty(256)
+        _chk(lib.cp_mg_gram(self._h, which, _dptr(V), _dptr(g)))
+        return g.reshape(16, 16)
+
+    def mg_power_start(self):
+        s = C.c_double()
+        _chk(lib.cp_mg_power_start(self._h, C.byref(s)))
+        return s.value
 
     # benchmarking hooks
     def iterate(self, theta, tau, sigma, iters):

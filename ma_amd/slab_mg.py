@@ -1,0 +1,214 @@
+"""Row-slab multi-GPU execution of the NN-TV hot path: one process per GPU over torch.distributed (RCCL).
+
+Per CP iteration:
+    k_mf_fused_tv on the rank's slab -> local reduction -> ONE all-gather of the reduced partials
+    (20 scalars + two K x K Gram matrices) -> every rank runs the identical fixed-order sum + eigensolve
+    (k_mf_efused) -> neighbour exchange of one halo column of u (x_n) and of y_{n+1}.
+No ring all-reduce: the payload is 4 KB, latency-bound, and the fixed-order local sum keeps all ranks bitwise identical.
+
+`SlabComm` is the communication layer (pure torch.distributed, works with gloo on CPU tensors -> tested without a GPU);
+`MultiGpuEngine` binds it to the cp_mg_* entry points of libcpengine.so.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import engine as E
+
+
+class SlabComm:
+    """neighbour halo exchange + all-gather for a 1-D chain of ranks (no wrap-around)"""
+
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
+        self.backend = dist.get_backend(group)
+        self.stage_cpu = (self.backend == "gloo")
+
+    def _wire(self, t):
+        # gloo cannot move device tensors: stage through host memory (only used in tests on a one-GPU box)
+        return t.cpu() if (self.stage_cpu and t.is_cuda) else t
+
+    def exchange(self, to_left=None, to_right=None, from_left=None, from_right=None):
+        """sends `to_left` to rank-1 and `to_right` to rank+1; fills `from_left` / `from_right` with what the
+        neighbours sent towards this rank. Buffers may be None at the ends of the chain or when a direction is unused."""
+        ops, post = [], []
+        if self.left is not None and to_left is not None:
+            ops.append(dist.P2POp(dist.isend, self._wire(to_left), self.left, self.group))
+        if self.right is not None and to_right is not None:
+            ops.append(dist.P2POp(dist.isend, self._wire(to_right), self.right, self.group))
+        if self.left is not None and from_left is not None:
+            buf = torch.empty_like(from_left, device="cpu") if (self.stage_cpu and from_left.is_cuda) else from_left
+            ops.append(dist.P2POp(dist.irecv, buf, self.left, self.group))
+            post.append((from_left, buf))
+        if self.right is not None and from_right is not None:
+            buf = torch.empty_like(from_right, device="cpu") if (self.stage_cpu and from_right.is_cuda) else from_right
+            ops.append(dist.P2POp(dist.irecv, buf, self.right, self.group))
+            post.append((from_right, buf))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for dst, buf in post:
+            if dst is not buf:
+                dst.copy_(buf)
+
+    def all_gather(self, gathered, mine):
+        """gathered: (world, len) tensor, row r = rank r's vector (fixed order -> deterministic reductions)"""
+        if self.stage_cpu and mine.is_cuda:
+            g = torch.empty(gathered.numel(), dtype=gathered.dtype)
+            dist.all_gather_into_tensor(g, mine.cpu(), group=self.group)
+            gathered.view(-1).copy_(g)
+        else:
+            dist.all_gather_into_tensor(gathered.view(-1), mine, group=self.group)
+
+    def all_reduce_sum(self, t):
+        w = self._wire(t)
+        dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
+        if w is not t:
+            t.copy_(w)
+        return t
+
+
+class MultiGpuEngine:
+    def __init__(self, model, m, n, k, bc, h, omega, mu, device, part, group=None):
+        if model != E.MODEL_MF_NN_TV:
+            raise E.CpEngineError("cpengine:unsupported row slabs are implemented for the NN-TV model")
+        self.part, self.m, self.n, self.k = part, m, n, k
+        self.dev = torch.device("cuda", device)
+        self.comm = SlabComm(part.rank, part.world, group)
+        self.eng = E.Engine(model, m, part.nl, k=k, bc=bc, h=h, omega=omega, mu=mu, device=device, n_global=n,
+                            j_offset=part.j0)
+        self.eng.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        plen = int(E.lib.cp_mg_partial_len())
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        self.red = torch.zeros(plen, **f64)
+        self.gathered = torch.zeros((part.world, plen), **f64)
+        self.hbuf = {}
+        for sel in (E.SEL_X_U, E.SEL_P_Y12, E.SEL_P_DY):
+            ln = self.eng.halo_len(sel)
+            self.hbuf[sel] = [torch.zeros(ln, **f64) for _ in range(2)]   # [send, recv]
+
+    # ---- halo exchanges ---------------------------------------------------------------------------
+    def _send_first_to_left(self, buf, sel):
+        """first owned column -> left neighbour's right halo"""
+        send, recv = self.hbuf[sel]
+        c = self.comm
+        if c.left is not None:
+            self.eng.halo_pack(buf, sel, 0, send.data_ptr())
+        c.exchange(to_left=send if c.left is not None else None, from_right=recv if c.right is not None else None)
+        if c.right is not None:
+            self.eng.halo_unpack(buf, sel, 1, recv.data_ptr())
+
+    def _send_last_to_right(self, buf, sel):
+        """last owned column -> right neighbour's left halo"""
+        send, recv = self.hbuf[sel]
+        c = self.comm
+        if c.right is not None:
+            self.eng.halo_pack(buf, sel, 1, send.data_ptr())
+        c.exchange(to_right=send if c.right is not None else None, from_left=recv if c.left is not None else None)
+        if c.left is not None:
+            self.eng.halo_unpack(buf, sel, 0, recv.data_ptr())
+
+    def exchange_x(self, buf):
+        self._send_first_to_left(buf, E.SEL_X_U)
+
+    def exchange_p(self, buf):
+        self._send_first_to_left(buf, E.SEL_P_Y12)
+        self._send_last_to_right(buf, E.SEL_P_DY)
+
+    # ---- engine facade ----------------------------------------------------------------------------
+    def set_images(self, imgs_full):
+        self.eng.set_images(imgs_full)
+
+    def set_primal(self, x0_local):
+        self.eng.set_primal(x0_local)
+        self.exchange_x(E.BUF_X0)
+
+    def set_dual(self, y0_local):
+        self.eng.set_dual(y0_local)
+
+    def linearize(self):
+        self.exchange_x(E.BUF_X0)
+        self.eng.linearize()
+
+    def set_nu(self, nu):
+        self.eng.set_nu(nu)
+
+    def singular_values(self, which):
+        """Gram -> eig, then a second Gram in the rotated basis (cf. cp_singular_values), Gram summed over ranks"""
+        def gram(V):
+            g = torch.from_numpy(self.eng.mg_gram(which, V).copy())
+            g = g.to(self.dev) if not self.comm.stage_cpu else g
+            self.comm.all_reduce_sum(g)
+            return g.cpu().numpy()
+        k = self.k
+        G = gram(None)
+        _, V1 = np.linalg.eigh(0.5 * (G[:k, :k] + G[:k, :k].T))
+        V = np.eye(16)
+        V[:k, :k] = V1
+        G2 = gram(V)
+        lam = np.linalg.eigvalsh(0.5 * (G2[:k, :k] + G2[:k, :k].T))
+        return np.sqrt(np.maximum(lam, 0.0))[::-1].copy()
+
+    def norm_estimate(self):
+        """NNE/matrix_norm.m:15-48 with halo exchanges around A and A' and a scalar all-reduce per step"""
+        ss = torch.tensor([self.eng.mg_power_start()], dtype=torch.float64)
+        ss = ss.to(self.dev) if not self.comm.stage_cpu else ss
+        self.comm.all_reduce_sum(ss)
+        scale = 1.0 / math.sqrt(float(ss.item()))
+        e = []
+        i = 0
+        while i < 2 or abs(e[i - 1] - e[i - 2]) > 1e-6 * e[i - 1]:
+            i += 1
+            self.exchange_x(E.BUF_X1)
+            self.eng.mg_stage(E.STAGE_APPLY_A, 0, self.red.data_ptr(), scale=scale)
+            self._send_last_to_right(E.BUF_P1, E.SEL_P_DY)
+            self.eng.mg_stage(E.STAGE_APPLY_AT, 0, self.red.data_ptr())
+            s = self.red[:1].clone()
+            self.comm.all_reduce_sum(s)
+            normY = math.sqrt(float(s.item()))
+            scale = 1.0 / normY
+            e.append(math.sqrt(normY))
+            if i == 100:
+                break
+        return e[-1], i
+
+    def iterate(self, theta, tau, sigma, iters, check_stop=0, tol=0.0):
+        """`iters` CP iterations from the canonical state (benchmark hook; the stop rule is off by default)"""
+        eng, w = self.eng, self.part.world
+        self.exchange_x(E.BUF_X0)
+        self.exchange_p(E.BUF_P0)
+        eng.mg_begin(theta, tau, sigma)
+        eng.mg_stage(E.STAGE_DUAL0, 0, self.red.data_ptr())
+        self.comm.all_gather(self.gathered, self.red)
+        eng.mg_stage(E.STAGE_EIG0, 0, self.gathered.data_ptr(), world=w)
+        self.exchange_p(E.BUF_P1)
+        for n in range(1, iters + 1):
+            eng.mg_stage(E.STAGE_FUSED, n, self.red.data_ptr())
+            self.comm.all_gather(self.gathered, self.red)
+            eng.mg_stage(E.STAGE_EFUSED, n, self.gathered.data_ptr(), world=w, check_stop=check_stop, tol=tol)
+            self.exchange_x(E.BUF_X0 + (n & 1))
+            self.exchange_p(E.BUF_P0 + ((n + 1) & 1))
+        self.iterations = iters
+        eng.mg_end(iters)
+
+    def sync(self):
+        self.eng.sync()
+
+    def kernel_time_ms(self, name):
+        return self.eng.kernel_time_ms(name)
+
+    def primal(self):
+        return self.eng.primal()
+
+    def dual(self):
+        return self.eng.dual()
+
+    def history(self):
+        return self.eng.history()
+
+    def close(self):
+        self.eng.close()

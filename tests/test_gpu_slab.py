@@ -1,0 +1,20 @@
+"""Row-slab multi-GPU path on ONE GPU: 2 and 3 ranks (gloo, device tensors staged through the host) against the
+single-handle result. The 8-GPU RCCL run itself belongs to the driver's scaling bench."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,k", [(2, 16), (3, 5)])
+def test_slabs_match_single_gpu(world, k):
+    env = dict(os.environ, SLAB_K=str(k), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29400 + world), os.path.join(ROOT, "tests", "slab_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0

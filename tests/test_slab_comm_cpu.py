@@ -1,0 +1,61 @@
+"""world_size-2/3 gloo tests (CPU) of the slab communication layer and partition used by the multi-GPU path."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, results):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ma_amd.slab_mg import SlabComm
+    from ma_amd.slab import Partition
+    c = SlabComm(rank, world)
+    ok = True
+    # halo exchange along the chain: first column -> left neighbour, last column -> right neighbour
+    n, m = 23, 5
+    part = Partition(n, world, rank)
+    field = torch.arange(n * m, dtype=torch.float64).reshape(n, m)          # global field, column j = row j here
+    mine = field[part.j0:part.j1]
+    from_left = torch.full((m,), -1.0, dtype=torch.float64)
+    from_right = torch.full((m,), -1.0, dtype=torch.float64)
+    c.exchange(to_left=mine[0].clone(), to_right=mine[-1].clone(), from_left=from_left, from_right=from_right)
+    if c.left is not None:
+        ok &= bool(torch.equal(from_left, field[part.j0 - 1]))
+    else:
+        ok &= bool((from_left == -1).all())
+    if c.right is not None:
+        ok &= bool(torch.equal(from_right, field[part.j1]))
+    else:
+        ok &= bool((from_right == -1).all())
+    # one-directional exchange (x halo: first column -> left neighbour's right halo only)
+    fr = torch.full((m,), -2.0, dtype=torch.float64)
+    c.exchange(to_left=mine[0].clone() if c.left is not None else None, from_right=fr if c.right is not None else None)
+    if c.right is not None:
+        ok &= bool(torch.equal(fr, field[part.j1]))
+    # all-gather in rank order and fixed-order sum -> identical on every rank
+    vec = torch.tensor([float(rank + 1), 10.0 ** rank, 1e-3 * rank], dtype=torch.float64)
+    g = torch.zeros((world, 3), dtype=torch.float64)
+    c.all_gather(g, vec)
+    for r in range(world):
+        ok &= bool(torch.equal(g[r], torch.tensor([float(r + 1), 10.0 ** r, 1e-3 * r], dtype=torch.float64)))
+    s = torch.tensor([float(rank)], dtype=torch.float64)
+    c.all_reduce_sum(s)
+    ok &= float(s.item()) == sum(range(world))
+    results[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_comm_gloo(world):
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, 29510 + world, results), nprocs=world, join=True)
+    assert all(results[r] for r in range(world)) and len(results) == world
