@@ -75,8 +75,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    # test hook for a one-GPU box: CP_BENCH_BACKEND=gloo puts every rank on device 0 and stages messages through the host
+    backend = os.environ.get("CP_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
@@ -119,15 +126,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    solver.iterate(1.0, tau, sigma, max(args.warmup, 1))
+    # one run of warmup + steps iterations: start-up (x_old = x0, the first dual step) before the warm-up, the timed
+    # region is exactly `steps` CP iterations, the state is brought back to canonical form after it
+    solver.iterate_begin(1.0, tau, sigma, args.warmup + args.steps)
+    solver.iterate_steps(args.warmup)
     solver.sync()
     solver.kernel_times()                                      # drop warm-up timings
     barrier()
     t0 = time.perf_counter()
-    solver.iterate(1.0, tau, sigma, args.steps)
+    solver.iterate_steps(args.steps)
     solver.sync()
     barrier()
     dt = time.perf_counter() - t0
+    solver.iterate_end()
+    solver.sync()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -155,6 +155,14 @@ int cp_downsample(cp_handle fine, cp_handle coarse);
  * state; cp_sync waits for them. cp_kernel_time_ms returns the accumulated HIP-event time and
  * launch count of the named pass ("dual", "primal", "eig", "fin") since the last call.       */
 int cp_iterate(cp_handle h, double theta, double tau, double sigma, int32_t iters);
+/* The same in three parts, for streaming callers and steady-state measurements:
+ *   cp_iterate_begin  start-up of a run of at most max_iters iterations (x_old = x0; NN-TV: the first dual step),
+ *   cp_iterate_steps  `iters` more iterations of PDO/chambolle_pock.m:156-179 and nothing else (may be called repeatedly),
+ *   cp_iterate_end    brings the state back to its canonical form (projected y3, mean-free u) for the accessors.
+ * Between begin and end every entry point that touches the state fails with CP_ERR_BAD_STATE.      */
+int cp_iterate_begin(cp_handle h, double theta, double tau, double sigma, int32_t max_iters);
+int cp_iterate_steps(cp_handle h, int32_t iters);
+int cp_iterate_end(cp_handle h);
 int cp_sync(cp_handle h);
 int cp_kernel_time_ms(cp_handle h, const char *pass, double *ms, int64_t *launches);
 

@@ -22,6 +22,9 @@ static thread_local std::string g_err;
         return (code);                                       \
     } while (0)
 
+#define CP_NOT_ITERATING(h) \
+    if ((h)->it_n >= 0) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState an iteration is open: call cp_iterate_end / cp_mg_end first")
+
 #define HIPCHK(expr)                                                                             \
     do {                                                                                         \
         hipError_t e_ = (expr);                                                                  \
@@ -68,6 +71,8 @@ struct cp_engine {
     int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU: two LDS tiles per wave)
     bool linearized = false, has_nu = false, has_images = false;
     hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless cp_set_stream)
+    int it_n = -1;                     // >= 0 between cp_iterate_begin / cp_mg_begin and the matching end: iterations done
+    bool it_mg = false;                // the open iteration was started by cp_mg_begin
     hipStream_t own_stream = nullptr;
     double mg_theta = 1.0, mg_tau = 0.0, mg_sigma = 0.0;
     double *red = nullptr;             // reduced partial vector of this rank (CP_PSTRIDE doubles)
@@ -287,6 +292,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
 extern "C" int cp_set_images(cp_handle h, const double *a, const double *b) {
     if (!h || !a) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle or image");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     const size_t imgN = (size_t)h->K * h->m * h->d.n_global * h->batch;
     if (!h->mf && h->gt == GT_SAD_DEN) {
         // the noisy image g plays the role of b (field layout), PDO/test_TV_L1_denoising.m:58
@@ -311,6 +317,7 @@ extern "C" int cp_set_images(cp_handle h, const double *a, const double *b) {
 static int set_state(cp_handle h, double *dev, const double *host, int nfields) {
     if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     return upload_fields(h, dev, host, nfields * h->batch);
 }
 extern "C" int cp_set_primal(cp_handle h, const double *x0) { return set_state(h, h ? h->X[0] : nullptr, x0, h ? h->nxf : 0); }
@@ -318,11 +325,13 @@ extern "C" int cp_set_dual(cp_handle h, const double *y0) { return set_state(h, 
 extern "C" int cp_get_primal(cp_handle h, double *x) {
     if (!h || !x) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle or buffer");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     return download_fields(h, h->X[0], x, h->nxf * h->batch);
 }
 extern "C" int cp_get_dual(cp_handle h, double *y) {
     if (!h || !y) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle or buffer");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     return download_fields(h, h->P[0], y, h->npf * h->batch);
 }
 
@@ -330,6 +339,7 @@ extern "C" int cp_get_dual(cp_handle h, double *y) {
 extern "C" int cp_linearize(cp_handle h, const double *u0) {
     if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     if (!h->mf && h->gt == GT_SAD_DEN) return CP_OK;   // nothing to linearise
     if (!h->has_images) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_linearize before cp_set_images");
     const double *xsrc = h->X[0];
@@ -394,6 +404,7 @@ extern "C" int cp_set_nu(cp_handle h, double nu) {
     if (!h || !h->mf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_set_nu needs an mf_nn handle");
     if (!(nu > 0.0)) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg nu must be positive");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     HIPCHK(hipMemcpyAsync(&((CpCtrl *)h->ctrl)->nu, &nu, sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->has_nu = true;
@@ -406,6 +417,7 @@ extern "C" int cp_set_nu(cp_handle h, double nu) {
 extern "C" int cp_singular_values(cp_handle h, int which, double *sv) {
     if (!h || !h->mf || !sv) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_singular_values needs an mf_nn handle");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     if (h->d.n_global != h->nl) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_singular_values on a slab");
     const double *field;
     if (which == 0) {
@@ -439,6 +451,7 @@ extern "C" int cp_singular_values(cp_handle h, int which, double *sv) {
 extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int32_t *iters) {
     if (!h || !h->mf || !est) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_norm_estimate needs an mf_nn handle");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_norm_estimate before cp_linearize");
     if (h->d.n_global != h->nl) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_norm_estimate on a slab");
     MfParams P = mf_params(h, 1.0, 1.0, 1.0);
@@ -770,6 +783,7 @@ extern "C" int cp_solve(cp_handle h, double theta, double tau, double sigma, int
     if (max_iter < 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg max_iter < 0");
     if (!(tau > 0.0) || !(sigma > 0.0)) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg step sizes must be positive");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     return h->mf ? solve_mf(h, theta, tau, sigma, max_iter, tol, res) : solve_pw(h, theta, tau, sigma, max_iter, tol, res);
 }
 
@@ -820,6 +834,8 @@ extern "C" int cp_prolong(cp_handle coarse, cp_handle fine, double factor) {
     if (fine->m > 2 * coarse->m || fine->nl > 2 * coarse->nl)
         CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg fine level larger than twice the coarse level");
     HIPCHK(hipSetDevice(fine->d.device));
+    CP_NOT_ITERATING(coarse);
+    CP_NOT_ITERATING(fine);
     HIPCHK(hipStreamSynchronize(coarse->stream));
     const int nf = fine->nxf * fine->batch;
     hipLaunchKernelGGL(k_prolong, dim3(2048), dim3(CP_BLOCK), 0, fine->stream, fine->m, fine->nl, fine->fs, coarse->m,
@@ -875,48 +891,83 @@ extern "C" int cp_get_images(cp_handle h, double *a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int cp_iterate(cp_handle h, double theta, double tau, double sigma, int32_t iters) {
+// benchmark / streaming hooks: begin (start-up: x_old = x0, first dual step of the fused path), any number of
+// cp_iterate_steps (steady-state iterations, nothing else), end (lazy state -> canonical X[0], P[0])
+static int iter_timer_slot(cp_engine *h) {
+    PassTimer &t = h->timers[T_ITER];
+    if (t.used + 2 > t.ev.size())
+        for (int a = 0; a < 2; ++a) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); t.ev.push_back(e); }
+    return CP_OK;
+}
+
+extern "C" int cp_iterate_begin(cp_handle h, double theta, double tau, double sigma, int32_t max_iters) {
     if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    if (max_iters < 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg max_iters < 0");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_iterate before cp_linearize");
-    CPCHK(ensure_hist(h, iters + 2));
-    h->profile = true;
+    if (h->mf && !h->has_nu) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_iterate before cp_set_nu");
+    CPCHK(ensure_hist(h, max_iters + 2));
+    h->mg_theta = theta; h->mg_tau = tau; h->mg_sigma = sigma;
     if (h->mf) {
-        if (!h->has_nu) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_iterate before cp_set_nu");
         const MfParams P = mf_params(h, theta, tau, sigma);
         CPCHK(mf_begin(h));
-        PassTimer &t = h->timers[T_ITER];
-        if (t.used + 2 > t.ev.size())
-            for (int a = 0; a < 2; ++a) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); t.ev.push_back(e); }
-        if (h->reg == 0) {
-            h->profile = false;
-            CPCHK(mf_fused_start(h, P, 0.0));
-            h->profile = true;
-        }
-        HIPCHK(hipEventRecord(t.ev[t.used], h->stream));
-        if (h->reg == 0) CPCHK(mf_fused_iterations(h, P, 0, iters, 0, 0.0));
-        else CPCHK(mf_iterations(h, P, 0, iters, 0, 0.0));
-        HIPCHK(hipEventRecord(t.ev[t.used + 1], h->stream));
-        t.used += 2;
-        CPCHK(mf_end(h, P, iters));
+        if (h->reg == 0) CPCHK(mf_fused_start(h, P, 0.0));
     } else {
-        const PwParams P = pw_params(h, theta, tau, sigma);
         HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(PwCtrl) * h->batch, h->stream));
         HIPCHK(hipMemcpyAsync(h->X[1], h->X[0], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));
-        PassTimer &t = h->timers[T_ITER];
-        if (t.used + 2 > t.ev.size())
-            for (int a = 0; a < 2; ++a) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); t.ev.push_back(e); }
-        HIPCHK(hipEventRecord(t.ev[t.used], h->stream));
-        CPCHK(pw_iterations(h, P, 0, iters, 0, 0.0));
-        HIPCHK(hipEventRecord(t.ev[t.used + 1], h->stream));
-        t.used += 2;
-        if (iters & 1) {
-            HIPCHK(hipMemcpyAsync(h->X[0], h->X[1], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(h->P[0], h->P[1], sizeof(double) * h->pN, hipMemcpyDeviceToDevice, h->stream));
-        }
     }
-    h->profile = false;
+    h->it_n = 0;
     return CP_OK;
+}
+
+extern "C" int cp_iterate_steps(cp_handle h, int32_t iters) {
+    if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    if (h->it_n < 0 || h->it_mg) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_iterate_steps without cp_iterate_begin");
+    if (iters < 0 || h->it_n + iters + 2 > h->hist_rows)
+        CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg %d more iterations exceed max_iters of cp_iterate_begin", iters);
+    h->profile = true;
+    CPCHK(iter_timer_slot(h));
+    PassTimer &t = h->timers[T_ITER];
+    HIPCHK(hipEventRecord(t.ev[t.used], h->stream));
+    if (h->mf) {
+        const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
+        if (h->reg == 0) CPCHK(mf_fused_iterations(h, P, h->it_n, iters, 0, 0.0));
+        else CPCHK(mf_iterations(h, P, h->it_n, iters, 0, 0.0));
+    } else {
+        const PwParams P = pw_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
+        CPCHK(pw_iterations(h, P, h->it_n, iters, 0, 0.0));
+    }
+    HIPCHK(hipEventRecord(t.ev[t.used + 1], h->stream));
+    t.used += 2;
+    h->profile = false;
+    h->it_n += iters;
+    return CP_OK;
+}
+
+extern "C" int cp_iterate_end(cp_handle h) {
+    if (!h) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
+    HIPCHK(hipSetDevice(h->d.device));
+    if (h->it_n < 0 || h->it_mg) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_iterate_end without cp_iterate_begin");
+    const int iters = h->it_n;
+    h->it_n = -1;
+    if (h->mf) {
+        const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
+        CPCHK(mf_end(h, P, iters));
+    } else if (iters & 1) {
+        HIPCHK(hipMemcpyAsync(h->X[0], h->X[1], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->P[0], h->P[1], sizeof(double) * h->pN, hipMemcpyDeviceToDevice, h->stream));
+    }
+    for (int pI = 0; pI < h->batch; ++pI) h->last[pI] = cp_result{iters, CP_STOP_MAXITER, iters + 1, h->hcols};
+    return CP_OK;
+}
+
+extern "C" int cp_iterate(cp_handle h, double theta, double tau, double sigma, int32_t iters) {
+    CPCHK(cp_iterate_begin(h, theta, tau, sigma, iters));
+    int rc = cp_iterate_steps(h, iters);
+    if (rc != CP_OK) { h->it_n = -1; return rc; }
+    return cp_iterate_end(h);
 }
 
 extern "C" int cp_sync(cp_handle h) {
@@ -1042,10 +1093,13 @@ extern "C" int cp_mg_halo_unpack(cp_handle h, int buf, int sel, int side, const 
 extern "C" int cp_mg_begin(cp_handle h, double theta, double tau, double sigma) {
     if (!h || !h->mf || h->reg != 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_begin needs an NN-TV handle");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     if (!h->linearized || !h->has_nu) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_begin before linearize / set_nu");
     h->mg_theta = theta; h->mg_tau = tau; h->mg_sigma = sigma;
     CPCHK(ensure_hist(h, 4096));
     h->profile = true;     // per-launch HIP events of the fused kernel (cp_kernel_time_ms)
+    h->it_n = 0;
+    h->it_mg = true;
     return mf_begin(h);
 }
 
@@ -1053,6 +1107,9 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
                            int32_t check_stop, double tol) {
     if (!h || !h->mf || h->reg != 0 || !dev_buf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_stage");
     HIPCHK(hipSetDevice(h->d.device));
+    const bool power = (stage == CP_STAGE_APPLY_A || stage == CP_STAGE_APPLY_AT);
+    if (!power && !(h->it_n >= 0 && h->it_mg)) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_stage without cp_mg_begin");
+    if (power && h->it_n >= 0) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState power-iteration stage while an iteration is open");
     const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
     CpCtrl *ctrl = (CpCtrl *)h->ctrl;
     switch (stage) {
@@ -1106,12 +1163,15 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
 extern "C" int cp_mg_end(cp_handle h, int32_t iterations) {
     if (!h || !h->mf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_end");
     HIPCHK(hipSetDevice(h->d.device));
+    if (!(h->it_n >= 0 && h->it_mg)) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_end without cp_mg_begin");
     const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
     int zero = 0;
     HIPCHK(hipMemcpyAsync(h->ctrl, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
     CPCHK(mf_end(h, P, iterations));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->profile = false;
+    h->it_n = -1;
+    h->it_mg = false;
     h->last[0] = cp_result{iterations, CP_STOP_MAXITER, iterations + 1, h->hcols};
     return CP_OK;
 }
@@ -1130,6 +1190,7 @@ extern "C" int cp_mg_stop_state(cp_handle h, int32_t *stopped, int32_t *stop_ite
 extern "C" int cp_mg_gram(cp_handle h, int which, const double *V, double *gram) {
     if (!h || !h->mf || !gram) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_gram");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     const double *field = (which == 0) ? h->Tu : h->X[0] + (size_t)2 * h->K * h->fs;
     if (which == 0 && !h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_gram(0) before cp_linearize");
     MfParams P = mf_params(h, 1.0, 1.0, 1.0);
@@ -1155,6 +1216,7 @@ extern "C" int cp_mg_gram(cp_handle h, int which, const double *V, double *gram)
 extern "C" int cp_mg_power_start(cp_handle h, double *local_sumsq) {
     if (!h || !h->mf || !local_sumsq) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_power_start");
     HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
     MfParams P = mf_params(h, 1.0, 1.0, 1.0);
     HIPCHK(hipMemsetAsync(h->X[1], 0, sizeof(double) * h->xN, h->stream));
     HIPCHK(hipMemsetAsync(h->xtmp, 0, sizeof(double) * h->xN, h->stream));

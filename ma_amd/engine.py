@@ -64,6 +64,9 @@ def _load():
         "cp_prolong": [vp, vp, C.c_double],
         "cp_downsample": [vp, vp],
         "cp_iterate": [vp, C.c_double, C.c_double, C.c_double, C.c_int32],
+        "cp_iterate_begin": [vp, C.c_double, C.c_double, C.c_double, C.c_int32],
+        "cp_iterate_steps": [vp, C.c_int32],
+        "cp_iterate_end": [vp],
         "cp_sync": [vp],
         "cp_kernel_time_ms": [vp, C.c_char_p, dp, C.POINTER(C.c_int64)],
         "cp_set_stream": [vp, vp],
@@ -91,7 +94,8 @@ lib = _load()
 EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_images", "cp_set_primal", "cp_set_dual",
             "cp_linearize", "cp_get_linearization", "cp_set_nu", "cp_singular_values", "cp_norm_estimate", "cp_solve",
             "cp_get_result", "cp_get_history", "cp_get_primal", "cp_get_dual", "cp_get_images", "cp_prolong",
-            "cp_downsample", "cp_iterate", "cp_sync", "cp_kernel_time_ms", "cp_set_stream", "cp_mg_partial_len",
+            "cp_downsample", "cp_iterate", "cp_iterate_begin", "cp_iterate_steps", "cp_iterate_end", "cp_sync",
+            "cp_kernel_time_ms", "cp_set_stream", "cp_mg_partial_len",
             "cp_mg_halo_len", "cp_mg_halo_pack", "cp_mg_halo_unpack", "cp_mg_begin", "cp_mg_stage", "cp_mg_end",
             "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start"]
 
@@ -286,6 +290,15 @@ class Engine:
     # benchmarking hooks
     def iterate(self, theta, tau, sigma, iters):
         _chk(lib.cp_iterate(self._h, theta, tau, sigma, int(iters)))
+
+    def iterate_begin(self, theta, tau, sigma, max_iters):
+        _chk(lib.cp_iterate_begin(self._h, theta, tau, sigma, int(max_iters)))
+
+    def iterate_steps(self, iters):
+        _chk(lib.cp_iterate_steps(self._h, int(iters)))
+
+    def iterate_end(self):
+        _chk(lib.cp_iterate_end(self._h))
 
     def sync(self):
         _chk(lib.cp_sync(self._h))

@@ -52,6 +52,15 @@ class SlabSolver:
     def iterate(self, theta, tau, sigma, iters):
         self.eng.iterate(theta, tau, sigma, iters)
 
+    def iterate_begin(self, theta, tau, sigma, max_iters):
+        self.eng.iterate_begin(theta, tau, sigma, max_iters)
+
+    def iterate_steps(self, iters):
+        self.eng.iterate_steps(iters)
+
+    def iterate_end(self):
+        self.eng.iterate_end()
+
     def sync(self):
         self.eng.sync()
 

@@ -32,9 +32,10 @@ class SlabComm:
         # gloo cannot move device tensors: stage through host memory (only used in tests on a one-GPU box)
         return t.cpu() if (self.stage_cpu and t.is_cuda) else t
 
-    def exchange(self, to_left=None, to_right=None, from_left=None, from_right=None):
-        """sends `to_left` to rank-1 and `to_right` to rank+1; fills `from_left` / `from_right` with what the
-        neighbours sent towards this rank. Buffers may be None at the ends of the chain or when a direction is unused."""
+    def exchange_begin(self, to_left=None, to_right=None, from_left=None, from_right=None):
+        """starts sending `to_left` to rank-1 and `to_right` to rank+1 and receiving into `from_left` / `from_right`
+        what the neighbours sent towards this rank; buffers may be None at the ends of the chain or when a direction
+        is unused. Returns a token for exchange_end (the transfers overlap whatever is enqueued in between)."""
         ops, post = [], []
         if self.left is not None and to_left is not None:
             ops.append(dist.P2POp(dist.isend, self._wire(to_left), self.left, self.group))
@@ -48,12 +49,19 @@ class SlabComm:
             buf = torch.empty_like(from_right, device="cpu") if (self.stage_cpu and from_right.is_cuda) else from_right
             ops.append(dist.P2POp(dist.irecv, buf, self.right, self.group))
             post.append((from_right, buf))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return works, post
+
+    def exchange_end(self, token):
+        works, post = token
+        for w in works:
+            w.wait()          # RCCL: the current stream waits, the host does not
         for dst, buf in post:
             if dst is not buf:
                 dst.copy_(buf)
+
+    def exchange(self, to_left=None, to_right=None, from_left=None, from_right=None):
+        self.exchange_end(self.exchange_begin(to_left, to_right, from_left, from_right))
 
     def all_gather(self, gathered, mine):
         """gathered: (world, len) tensor, row r = rank r's vector (fixed order -> deterministic reductions)"""
@@ -90,6 +98,12 @@ class MultiGpuEngine:
         for sel in (E.SEL_X_U, E.SEL_P_Y12, E.SEL_P_DY):
             ln = self.eng.halo_len(sel)
             self.hbuf[sel] = [torch.zeros(ln, **f64) for _ in range(2)]   # [send, recv]
+        self.len_xu, self.len_py = self.eng.halo_len(E.SEL_X_U), self.eng.halo_len(E.SEL_P_Y12)
+        ldy = self.eng.halo_len(E.SEL_P_DY)
+        self.s_left = torch.zeros(self.len_xu + self.len_py, **f64)     # -> left neighbour's right halo
+        self.r_right = torch.zeros(self.len_xu + self.len_py, **f64)    # <- right neighbour's first column
+        self.s_right = torch.zeros(ldy, **f64)                          # -> right neighbour's left halo
+        self.r_left = torch.zeros(ldy, **f64)                           # <- left neighbour's last column
 
     # ---- halo exchanges ---------------------------------------------------------------------------
     def _send_first_to_left(self, buf, sel):
@@ -118,6 +132,32 @@ class MultiGpuEngine:
     def exchange_p(self, buf):
         self._send_first_to_left(buf, E.SEL_P_Y12)
         self._send_last_to_right(buf, E.SEL_P_DY)
+
+    def exchange_state_pack(self, xbuf, pbuf):
+        """one message per neighbour and iteration: [u of x_n | y1, y2 of y_{n+1}] of the first owned column goes left,
+        the Dy components of y2 of the last owned column go right"""
+        c, eng = self.comm, self.eng
+        if c.left is not None:
+            eng.halo_pack(xbuf, E.SEL_X_U, 0, self.s_left.data_ptr())
+            eng.halo_pack(pbuf, E.SEL_P_Y12, 0, self.s_left.data_ptr() + 8 * self.len_xu)
+        if c.right is not None:
+            eng.halo_pack(pbuf, E.SEL_P_DY, 1, self.s_right.data_ptr())
+
+    def exchange_state_begin(self):
+        c = self.comm
+        return c.exchange_begin(to_left=self.s_left if c.left is not None else None,
+                                to_right=self.s_right if c.right is not None else None,
+                                from_left=self.r_left if c.left is not None else None,
+                                from_right=self.r_right if c.right is not None else None)
+
+    def exchange_state_end(self, token, xbuf, pbuf):
+        c, eng = self.comm, self.eng
+        c.exchange_end(token)
+        if c.right is not None:
+            eng.halo_unpack(xbuf, E.SEL_X_U, 1, self.r_right.data_ptr())
+            eng.halo_unpack(pbuf, E.SEL_P_Y12, 1, self.r_right.data_ptr() + 8 * self.len_xu)
+        if c.left is not None:
+            eng.halo_unpack(pbuf, E.SEL_P_DY, 0, self.r_left.data_ptr())
 
     # ---- engine facade ----------------------------------------------------------------------------
     def set_images(self, imgs_full):
@@ -176,8 +216,8 @@ class MultiGpuEngine:
                 break
         return e[-1], i
 
-    def iterate(self, theta, tau, sigma, iters, check_stop=0, tol=0.0):
-        """`iters` CP iterations from the canonical state (benchmark hook; the stop rule is off by default)"""
+    def iterate_begin(self, theta, tau, sigma, max_iters=4000):
+        """start-up: halos of the canonical state, first dual step (y_1), W_1"""
         eng, w = self.eng, self.part.world
         self.exchange_x(E.BUF_X0)
         self.exchange_p(E.BUF_P0)
@@ -186,14 +226,31 @@ class MultiGpuEngine:
         self.comm.all_gather(self.gathered, self.red)
         eng.mg_stage(E.STAGE_EIG0, 0, self.gathered.data_ptr(), world=w)
         self.exchange_p(E.BUF_P1)
-        for n in range(1, iters + 1):
+        self.it_n = 0
+
+    def iterate_steps(self, iters, check_stop=0, tol=0.0):
+        """`iters` more CP iterations; per iteration: fused pass, all-gather of the reduced partials, eigensolve, and
+        one halo message per neighbour that is in flight during the eigensolve"""
+        eng, w = self.eng, self.part.world
+        for n in range(self.it_n + 1, self.it_n + iters + 1):
+            xb, pb = E.BUF_X0 + (n & 1), E.BUF_P0 + ((n + 1) & 1)
             eng.mg_stage(E.STAGE_FUSED, n, self.red.data_ptr())
+            self.exchange_state_pack(xb, pb)
             self.comm.all_gather(self.gathered, self.red)
+            tok = self.exchange_state_begin()
             eng.mg_stage(E.STAGE_EFUSED, n, self.gathered.data_ptr(), world=w, check_stop=check_stop, tol=tol)
-            self.exchange_x(E.BUF_X0 + (n & 1))
-            self.exchange_p(E.BUF_P0 + ((n + 1) & 1))
-        self.iterations = iters
-        eng.mg_end(iters)
+            self.exchange_state_end(tok, xb, pb)
+        self.it_n += iters
+
+    def iterate_end(self):
+        self.eng.mg_end(self.it_n)
+        self.iterations = self.it_n
+
+    def iterate(self, theta, tau, sigma, iters, check_stop=0, tol=0.0):
+        """`iters` CP iterations from the canonical state (benchmark hook; the stop rule is off by default)"""
+        self.iterate_begin(theta, tau, sigma)
+        self.iterate_steps(iters, check_stop, tol)
+        self.iterate_end()
 
     def sync(self):
         self.eng.sync()

@@ -1,0 +1,140 @@
+"""HIP engine through the C ABI vs the committed fixtures of tests/golden/ (no oracle code runs here: the fixtures are
+the oracle's outputs for inputs that include the data files the reference ships, see tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300)
+
+
+def _vecF(a):
+    return np.asarray(a, dtype=np.float64).reshape(-1, order="F")
+
+
+def test_warp_fixture(golden_dir):
+    """IRE/evaluate_displacement.m: warped image and gradient on Data/rect_2.png, displacements far outside the domain
+    and exactly on cell boundaries; coarse-level call with h_grid = image spacing"""
+    from ma_amd import engine as E
+    f = _load(golden_dir, "warp.npz")
+    T = f["T"]
+    m, n = T.shape
+    eng = E.Engine(E.MODEL_TV_L1_REG, m, n, lam=1.0)
+    eng.set_images(_vecF(T), _vecF(T))
+    eng.linearize(_vecF(f["u"]))
+    Tg, gg, _ = eng.get_linearization()
+    eng.close()
+    np.testing.assert_allclose(Tg, _vecF(f["Tu"]), rtol=0, atol=1e-15)
+    np.testing.assert_allclose(gg, _vecF(f["g"]), rtol=0, atol=1e-14)
+    assert np.array_equal(Tg == 0.0, _vecF(f["Tu"]) == 0.0)
+    Tc = f["Tc"]
+    mc, nc = Tc.shape
+    eng = E.Engine(E.MODEL_TV_L1_REG, mc, nc, h=tuple(f["hg"]), omega=[0.0, float(m), 0.0, float(n)], lam=1.0)
+    eng.set_images(_vecF(Tc), _vecF(Tc))
+    eng.linearize(_vecF(f["uc"]))
+    Tg, gg, _ = eng.get_linearization()
+    eng.close()
+    np.testing.assert_allclose(Tg, _vecF(f["Tcu"]), rtol=0, atol=1e-15)
+    np.testing.assert_allclose(gg, _vecF(f["gc"]), rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize("m,n", [(9, 6), (8, 8), (7, 11)])
+def test_pyramid_fixture(golden_dir, m, n):
+    """conv2 + subsampling of the image pyramid and kron(x, ones(2)) prolongation (NNE/mf_nn_tv...:75-76, 113-119),
+    odd and even sizes"""
+    from ma_amd import engine as E
+    f = _load(golden_dir, "pyramid.npz")
+    a, d = f[f"img_{m}x{n}"], f[f"down_{m}x{n}"]
+    mc, nc = d.shape
+    fine = E.Engine(E.MODEL_TV_L1_REG, m, n, lam=1.0)
+    coarse = E.Engine(E.MODEL_TV_L1_REG, mc, nc, lam=1.0)
+    fine.set_images(_vecF(a), _vecF(a))
+    fine.downsample_to(coarse)
+    np.testing.assert_allclose(coarse.images()[:mc * nc], _vecF(d), rtol=0, atol=1e-15)
+    coarse.set_primal(f[f"xlow_{m}x{n}"])
+    fine.prolong_from(coarse, 1.0)
+    assert np.array_equal(fine.primal(), f[f"prol_{m}x{n}"])
+    fine.close()
+    coarse.close()
+
+
+@pytest.mark.parametrize("tag,a,b,term", [("tvl1_rect", "rect_1", "rect_2", "SAD"),
+                                          ("tvl2_rir", "rect_in_rect_1", "rect_in_rect_2", "SSD"),
+                                          ("tvl1_slide", "sliding_rect_1", "sliding_rect_2", "SAD")])
+def test_pairwise_steps_fixture(golden_dir, tag, a, b, term):
+    """PDO/test_TV_L1_registration.m / test_TV_L2_registration.m on the reference's own Data/*.png: outer steps 0, 2
+    and 20, each started from the stored state (linearise, 25-30 CP iterations, histories, stop rule)"""
+    from ma_amd import engine as E
+    from ma_amd.drivers import normalize
+    f = _load(golden_dir, "pairwise_e2e.npz")
+    png = _load(golden_dir, "data_png.npz")
+    R = normalize(png[a].astype(np.float64))
+    T = normalize(png[b].astype(np.float64))
+    m, n = R.shape
+    lam, tau, iters, _ = f[f"{tag}_par"]
+    sigma = (1 - 1e-4) / (8 * tau)
+    eng = E.Engine(E.MODEL_TV_L1_REG if term == "SAD" else E.MODEL_TV_L2_REG, m, n, lam=float(lam))
+    eng.set_images(_vecF(T), _vecF(R))
+    for s in (0, 2, 20):
+        eng.set_primal(f[f"{tag}_s{s}_u0"])
+        eng.set_dual(f[f"{tag}_s{s}_v0"])
+        eng.linearize()
+        eng.solve(1.0, float(tau), sigma, int(iters), 1e-3)
+        ph, dh = eng.history()
+        phr, dhr = f[f"{tag}_s{s}_ph"], f[f"{tag}_s{s}_dh"]
+        assert ph.shape == phr.shape, (s, ph.shape, phr.shape)
+        np.testing.assert_allclose(ph, phr, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(dh, dhr, rtol=1e-9, atol=1e-6 * max(1.0, np.abs(dhr).max()))
+        assert _rel(eng.primal(), f[f"{tag}_s{s}_u"]) < TOL, s
+        assert _rel(eng.dual(), f[f"{tag}_s{s}_v"]) < TOL, s
+    eng.close()
+
+
+def test_c1_denoising_fixture(golden_dir):
+    """PDO/test_TV_L1_denoising.m on Data/rect1.png with the committed salt & pepper mask, 1000 iterations"""
+    from ma_amd import drivers as D
+    f = _load(golden_dir, "pairwise_e2e.npz")
+    x, y, ph, dh, _ = D.tv_l1_denoising(f["c1_noisy"], lam=1.5, tau=0.02, maxIter=1000, tol=1e-5)
+    assert ph.shape == f["c1_ph"].shape
+    np.testing.assert_allclose(ph, f["c1_ph"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(dh, f["c1_dh"], rtol=1e-9, atol=1e-9)
+    assert _rel(x, f["c1_x"]) < TOL and _rel(y, f["c1_y"]) < TOL
+
+
+@pytest.mark.parametrize("reg,bc,mu", [("tv", "neumann", 0.2), ("curvature", "dirichlet", 20.0)])
+def test_mfnn_driver_fixture(golden_dir, reg, bc, mu):
+    """NNE/mf_nn_{tv,curvature}_registration_no_ref_ml.m end to end (2 levels, outer iterations, nu schedule, power
+    iteration, histories) against the stored run"""
+    from ma_amd import drivers as D
+    f = _load(golden_dir, "mfnn_e2e.npz")
+    imgs = f["imgs"]
+    k = imgs.shape[0]
+    opt = dict(theta=1.0, maxIter=60, tol=1e-3, outerIter=[3, 2], mu=mu, nu_factor=[0.9, 0.9], bc=bc)
+    keep = {}
+    u, L, SV = D._mf_nn_ml([imgs[i] for i in range(k)], opt, reg, keep=keep)
+    levels = int(f[f"{reg}_levels"][0])
+    assert len(u) == levels
+    for lev in range(levels):
+        np.testing.assert_allclose(SV[lev], f[f"{reg}_SV{lev}"], rtol=1e-9, atol=1e-10)
+        for o in range(len(u[lev])):
+            key = f"{reg}_u_{lev}_{o}"
+            if key not in f:
+                assert u[lev][o] is None
+                continue
+            nu, tau, norm_est, n_power, rows = f[f"{reg}_sched_{lev}_{o}"]
+            kk = keep[(lev, o)]
+            assert abs(kk["nu"] - nu) <= 1e-11 * abs(nu) and abs(kk["norm_est"] - norm_est) <= 1e-11 * norm_est
+            assert kk["n_power"] == int(n_power) and kk["primal_history"].shape[0] == int(rows)
+            np.testing.assert_allclose(kk["primal_history"][:, :5], f[f"{reg}_ph_{lev}_{o}"][:, :5], rtol=1e-8, atol=1e-9)
+            np.testing.assert_allclose(kk["dual_history"][:, :5], f[f"{reg}_dh_{lev}_{o}"][:, :5], rtol=1e-8, atol=1e-9)
+            assert _rel(u[lev][o], f[key]) < 1e-9, (lev, o)
+            assert _rel(L[lev][o], f[f"{reg}_L_{lev}_{o}"]) < 1e-9, (lev, o)

@@ -70,3 +70,36 @@ def test_solve_matches_oracle(reg, bc, m, n, k):
     np.testing.assert_allclose(dh[:, :5], dhr[:, :5], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(ph[:, 5:], phr[:, 5:], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(dh[:, 5:], dhr[:, 5:], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("reg,k", [("tv", 16), ("tv", 5), ("curvature", 4)])
+def test_iterate_in_parts_is_bitwise_iterate(reg, k):
+    """cp_iterate_begin / cp_iterate_steps (twice) / cp_iterate_end == cp_iterate; the open iteration locks the state"""
+    from ma_amd import engine as E
+    m, n = 40, 36
+    imgs, u0, omega, h, A, b, T_u, gs = _setup(m, n, k, reg, "neumann")
+    model = E.MODEL_MF_NN_TV if reg == "tv" else E.MODEL_MF_NN_CURV
+    mu = 0.2 if reg == "tv" else 20.0
+    x0 = np.concatenate([u0.reshape(-1), 0.5 * T_u.reshape(-1, order="F")])
+    out = []
+    for parts in (None, (4, 7)):
+        eng = E.Engine(model, m, n, k=k, bc="neumann", h=h, omega=omega, mu=mu)
+        eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+        eng.set_primal(x0)
+        eng.linearize()
+        eng.set_nu(2.0 * k)
+        if parts is None:
+            eng.iterate(1.0, 0.2, 0.2, 11)
+        else:
+            eng.iterate_begin(1.0, 0.2, 0.2, 11)
+            eng.iterate_steps(parts[0])
+            with pytest.raises(E.CpEngineError, match="badState"):
+                eng.primal()
+            eng.iterate_steps(parts[1])
+            with pytest.raises(E.CpEngineError, match="badArg"):
+                eng.iterate_steps(1)
+            eng.iterate_end()
+        eng.sync()
+        out.append((eng.primal(), eng.dual()))
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
