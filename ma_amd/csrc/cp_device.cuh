@@ -151,6 +151,75 @@ __device__ __forceinline__ void svt_2x2(double a, double c, double b, double d, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Uniform base (SGPR pair) + 32-bit per-lane byte offset + immediate: the global_load/store "saddr" form. One VGPR per
+// distinct offset instead of a 64-bit VGPR address per access, and no per-access 64-bit VALU address arithmetic.
+// `ubase` must be wave-uniform; a field is < 4 GiB so the byte offset fits 32 bits.
+__device__ __forceinline__ double ldo(const double *__restrict__ ubase, unsigned off, int delta = 0) {
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(ubase) + (size_t)off + (ptrdiff_t)delta);
+}
+__device__ __forceinline__ void sto(double *__restrict__ ubase, unsigned off, double v) {
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(ubase) + (size_t)off) = v;
+}
+
+// sqrt(x) and 1/sqrt(x) from one v_rsq_f64 and the Goldschmidt / residual steps of the compiler's own f64 sqrt
+// expansion, without its range scaling: arguments here are sums of squares of image-scale quantities. Below 1e-280
+// (in practice: exactly 0) both results are 0.
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &sq, double &inv) {
+    const bool ok = x >= 1.0e-280;
+    const double xs = ok ? x : 1.0;
+    const double y0 = __builtin_amdgcn_rsq(xs);
+    double g = xs * y0, h = 0.5 * y0;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, xs);
+    g = fma(d, h, g);
+    d = fma(-g, g, xs);
+    g = fma(d, h, g);                       // sqrt(x), correctly rounded up to the last step's rounding
+    double iv = h + h;
+    const double e = fma(-g, iv, 1.0);
+    iv = fma(iv, e, iv);                    // 1/sqrt(x) to ~1 ulp
+    sq = ok ? g : 0.0;
+    inv = ok ? iv : 0.0;
+}
+
+// 2x2 matrices M = (m11, m21, m12, m22) split into a scaled rotation [E -H; H E]/2 and a scaled reflection [F G; G -F]/2
+// with E = m11+m22, H = m21-m12, F = m11-m22, G = m21+m12. With Q = |(E,H)|, R = |(F,G)|: the singular values are
+// (Q+R)/2 and |Q-R|/2, the singular vectors depend only on the two directions. Hence
+//   nuclear norm            = max(Q, R)
+//   U diag(f1, f2) V'       = p/Q [E -H; H E] + q/R [F G; G -F],  p = (f1 + d f2)/2, q = (f1 - d f2)/2, d = sign(Q - R)
+// for any f that is a function of the singular values (unique when Q or R vanish since then f1 = f2 matters only through
+// the surviving part). Same values as NNE/svd_2x2.m + pointwise_2x2_nn.m up to rounding, from 2 rsqrt instead of 10 sqrt
+// and 7 divisions.
+__device__ __forceinline__ double nuc_2x2(double m11, double m21, double m12, double m22) {
+    const double E = m11 + m22, H = m21 - m12, F = m11 - m22, G = m21 + m12;
+    double sq, inv;
+    sqrt_rsqrt(fmax(fma(E, E, H * H), fma(F, F, G * G)), sq, inv);
+    return sq;
+}
+
+// y - sigma * prox_{(mu/sigma)||.||_*}(y / sigma) = projection of y onto {largest singular value <= mu}
+// (NNE/pointwise_2x2_nn.m:46-48 via Moreau, positively homogeneous in sigma). s1 = largest singular value of the result.
+__device__ __forceinline__ void proj_spectral_2x2(double m11, double m21, double m12, double m22, double mu,
+                                                  double &r11, double &r21, double &r12, double &r22, double &s1) {
+    const double E = m11 + m22, H = m21 - m12, F = m11 - m22, G = m21 + m12;
+    double Q, iQ, R, iR;
+    sqrt_rsqrt(fma(E, E, H * H), Q, iQ);
+    sqrt_rsqrt(fma(F, F, G * G), R, iR);
+    const double sv1 = 0.5 * (Q + R), sv2 = 0.5 * fabs(Q - R);
+    const bool inside = sv1 <= mu;
+    const double f2 = fmin(sv2, mu);
+    const double df2 = (Q >= R) ? f2 : -f2;
+    const double cq = 0.5 * (mu + df2) * iQ, cr = 0.5 * (mu - df2) * iR;
+    const double qe = cq * E, qh = cq * H;
+    r11 = inside ? m11 : fma(cr, F, qe);
+    r22 = inside ? m22 : fma(-cr, F, qe);
+    r21 = inside ? m21 : fma(cr, G, qh);
+    r12 = inside ? m12 : fma(cr, G, -qh);
+    s1 = inside ? sv1 : mu;
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward difference along one axis with the reference's boundary rows
 // (NNE/finite_difference_operator.m:29-36): interior (u_next - u)/h; last row neumann 0,
 // linear u - u_prev (unscaled).

@@ -19,45 +19,51 @@
 #pragma once
 #include "cp_mfnn_small.cuh"
 
-// u_n = (u_{n-1} - tau*(A'y_n)_u) - mean  and  u_{n-1} at position (i, jg) (element offset e) of image k;
-// w = -(A'y_n)_u is returned for the G* monitors.
-// All loads are unconditional (every field has a halo column on both sides, so e-1, e+1, e-m, e+m are always inside
-// the allocation); boundary handling happens in the arithmetic. This keeps the whole per-image body one basic block, so
-// the compiler can issue every load of the three positions before the first wait.
+// Byte offsets of the positions one thread touches (see ldo(): uniform field base + 32-bit lane offset).
+struct PixOff {
+    unsigned c, cm;      // (i, j) and (i, j-1)
+};
+
+// u_n = (u_{n-1} - tau*(A'y_n)_u) - mean  and  u_{n-1} at position (i, jg) of one image; w = -(A'y_n)_u is returned for
+// the G* monitors. y1k, y2k, gxk, uxk: uniform bases of the image's y1, first y2 component, grad-x and u_x fields
+// (grad-y / u_y one field further, the y2 components fs apart).
+// All loads are unconditional (every field has a halo column on both sides, so the +-1 element and +-1 column
+// neighbours are always inside the allocation); boundary handling happens in the arithmetic. This keeps the whole
+// per-image body one basic block, so the compiler can issue every load of the three positions before the first wait.
 template <bool LINEAR>
-__device__ __forceinline__ void primal_u_at(const MfParams &P, int k, int i, int jg, int e,
-                                            const double *__restrict__ xo, const double *__restrict__ p,
-                                            const double *__restrict__ g, double cnx, double cny,
+__device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, PixOff o, unsigned fsb,
+                                            const double *__restrict__ y1k, const double *__restrict__ y2k,
+                                            const double *__restrict__ gxk, const double *__restrict__ uxk,
+                                            double cnx, double cny,
                                             double &uxn, double &uyn, double &uxo, double &uyo, double &wx, double &wy) {
-    const int K = P.K, m = P.m, fs = P.fs;
-    const double y1 = p[(size_t)k * fs + e];
-    const double gx = g[(size_t)(2 * k) * fs + e], gy = g[(size_t)(2 * k + 1) * fs + e];
-    const double *y2 = p + (size_t)(K + 4 * k) * fs + e;
+    const int m = P.m;
+    const double y1 = ldo(y1k, o.c);
+    const double gx = ldo(gxk, o.c), gy = ldo(gxk + P.fs, o.c);
     double adj[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const double *f = y2 + (size_t)c * fs;
-        const double wc = f[0];
+        const double *f = y2k + (size_t)c * P.fs;
+        const double wc = ldo(f, o.c);
         if ((c & 1) == 0) {   // Dx component: adjoint along i
-            const double wraw = f[-1];
+            const double wraw = ldo(f, o.c, -8);
             const double wm = (i >= 1) ? wraw : 0.0;
-            const double wl = LINEAR ? f[(m - 1) - i] : 0.0;
+            const double wl = LINEAR ? ldo(f, o.c + 8u * (unsigned)((m - 1) - i)) : 0.0;
             adj[c] = fwd_diff_adj(wc, wm, wl, i, m, LINEAR, P.inv_h1);
         } else {              // Dy component: adjoint along j
-            const double wraw = f[-m];
+            const double wraw = ldo(f, o.cm);
             const double wm = (jg >= 1) ? wraw : 0.0;
             double wl = 0.0;
             if (LINEAR) {
                 const int dj = (jg >= P.n_global - 2) ? (P.n_global - 1) - jg : 0;
-                wl = f[(size_t)dj * m];
+                wl = ldo(f, o.c + 8u * (unsigned)(dj * m));
             }
             adj[c] = fwd_diff_adj(wc, wm, wl, jg, P.n_global, LINEAR, P.inv_h2);
         }
     }
     const double vux = -gx * y1 + (adj[0] + adj[1]);
     const double vuy = -gy * y1 + (adj[2] + adj[3]);
-    uxo = xo[(size_t)(2 * k) * fs + e];
-    uyo = xo[(size_t)(2 * k + 1) * fs + e];
+    uxo = ldo(uxk, o.c);
+    uyo = ldo(uxk + P.fs, o.c);
     uxn = (uxo - P.tau * vux) - cnx;          // NNE/mean_zero_indicator.m:50
     uyn = (uyo - P.tau * vuy) - cny;          // :53
     wx = -vux;
@@ -65,25 +71,29 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int k, int i, int
 }
 
 template <bool LINEAR, bool FULLK>
-__global__ __launch_bounds__(CP_BLOCK) void k_mf_fused_tv(MfParams P, const double *__restrict__ xo,
-                                                          double *__restrict__ xn, const double *__restrict__ pin,
-                                                          double *__restrict__ pout, const double *__restrict__ g,
-                                                          const double *__restrict__ b, const double *__restrict__ W,
-                                                          const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
+__global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const double *__restrict__ xo,
+                                                             double *__restrict__ xn, const double *__restrict__ pin,
+                                                             double *__restrict__ pout, const double *__restrict__ g,
+                                                             const double *__restrict__ b, const double *__restrict__ W,
+                                                             const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
     __shared__ double tiles[CP_WAVES * 2 * 16 * CP_TS];
     __shared__ double red[CP_WAVES * CP_NSCAL];
     __shared__ double Wl[CP_KMAX * CP_KMAX];
     if (ctrl->stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *tileA = tiles + wave * 2 * 16 * CP_TS, *tileB = tileA + 16 * CP_TS;
-    const int K = P.K, m = P.m, fs = P.fs;
+    const int K = P.K, m = P.m;
+    const size_t fs = (size_t)P.fs;
     const bool linear = LINEAR;
     stage_W(W, Wl);
     __syncthreads();
     const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
     const double sigma = P.sigma, tau = P.tau, theta = P.theta, inv_sigma = 1.0 / P.sigma;
-    const double *y3in = pin + (size_t)(5 * K) * fs;
-    double *y3out = pout + (size_t)(5 * K) * fs;
+    const double *y3in = pin + 5 * (size_t)K * fs;
+    double *y3out = pout + 5 * (size_t)K * fs;
+    const double *Lin = xo + 2 * (size_t)K * fs;
+    double *Lout = xn + 2 * (size_t)K * fs;
+    const unsigned mb = 8u * (unsigned)m, fsb = 8u * (unsigned)P.fs;
 
     double sums[CP_NSUM], maxs[CP_NMAX];
 #pragma unroll
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_fused_tv(MfParams P, const doub
         const bool valid = (base + tid) < P.npix;
         const int q = valid ? base + tid : P.npix - 1;   // lanes past the end redo the last pixel, nothing is stored
         const int j = q / m, i = q - j * m;
-        const int e = q + m;
+        const unsigned off = 8u * (unsigned)(q + m);     // byte offset of (i, j) inside a field (halo column first)
         const int jg = P.j_off + j;
         const bool last_i = (i == m - 1), last_j = (jg == P.n_global - 1);
 
@@ -111,9 +121,9 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_fused_tv(MfParams P, const doub
 #pragma unroll
             for (int k = 0; k < CP_KMAX; ++k) {
                 const int kk = (FULLK || k < K) ? k : K - 1;
-                t3[k] = y3in[(size_t)kk * fs + e];
-                y1v[k] = pin[(size_t)kk * fs + e];
-                Lr[k] = xo[(size_t)(2 * K + kk) * fs + e];
+                t3[k] = ldo(y3in + (size_t)kk * fs, off);
+                y1v[k] = ldo(pin + (size_t)kk * fs, off);
+                Lr[k] = ldo(Lin + (size_t)kk * fs, off);
             }
 #pragma unroll
             for (int kp = 0; kp < CP_KMAX; ++kp) a[kp] = 0.0;
@@ -151,8 +161,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_fused_tv(MfParams P, const doub
             const double v = (valid && act) ? a[k] - smb : 0.0;       // y3~_{n+1} = y3_n + sigma*B*Lbar
             tileA[k * CP_TS + lane] = v;
             if (valid && act) {
-                y3out[(size_t)k * fs + e] = v;
-                xn[(size_t)(2 * K + k) * fs + e] = Lr[k];
+                sto(y3out + (size_t)k * fs, off, v);
+                sto(Lout + (size_t)k * fs, off, Lr[k]);
             }
         }
         __syncthreads();
@@ -168,24 +178,29 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_fused_tv(MfParams P, const doub
         for (int k = 0; k < CP_KMAX; ++k) tileA[k * CP_TS + lane] = Lr[k];
 
         // ---- phase 2: per image: displacement part of the primal step (own pixel + 2 neighbours), dual step ----
+        // neighbours along i and j ("previous" instead of "next" on a linear boundary row; unused otherwise)
         const int oi = (last_i && LINEAR) ? -1 : 1, oj = (last_j && LINEAR) ? -1 : 1;
+        const PixOff p0 = {off, off - mb};
+        const PixOff pi = {oi > 0 ? off + 8u : off - 8u, (oi > 0 ? off + 8u : off - 8u) - mb};
+        const PixOff pj = {oj > 0 ? off + mb : off - mb, oj > 0 ? off : off - 2u * mb};
         const double vmask = valid ? 1.0 : 0.0;
         for (int k = 0; k < K; ++k) {
+            const double *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
+            const double *gxk = g + 2 * (size_t)k * fs, *uxk = xo + 2 * (size_t)k * fs;
             const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
             double ux, uy, uxo_, uyo_, wx, wy, uxi, uyi, oi0, oi1, uxj, uyj, oj0, oj1, wd0, wd1;
-            primal_u_at<LINEAR>(P, k, i, jg, e, xo, pin, g, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
-            // neighbours along i and j ("previous" instead of "next" on a linear boundary row; unused otherwise)
-            primal_u_at<LINEAR>(P, k, i + oi, jg, e + oi, xo, pin, g, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
-            primal_u_at<LINEAR>(P, k, i, jg + oj, e + oj * m, xo, pin, g, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
-            const double gx = g[(size_t)(2 * k) * fs + e], gy = g[(size_t)(2 * k + 1) * fs + e];
-            const double bb = b[(size_t)k * fs + e];
-            const double y1 = pin[(size_t)k * fs + e];
-            const double *y2 = pin + (size_t)(K + 4 * k) * fs + e;
-            const double v0 = y2[0], v1 = y2[(size_t)fs], v2 = y2[2 * (size_t)fs], v3 = y2[3 * (size_t)fs];
+            primal_u_at<LINEAR>(P, i, jg, p0, fsb, y1k, y2k, gxk, uxk, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
+            primal_u_at<LINEAR>(P, i + oi, jg, pi, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
+            primal_u_at<LINEAR>(P, i, jg + oj, pj, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
+            const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
+            const double bb = ldo(b + (size_t)k * fs, off);
+            const double y1 = ldo(y1k, off);
+            const double v0 = ldo(y2k, off), v1 = ldo(y2k + fs, off), v2 = ldo(y2k + 2 * fs, off), v3 = ldo(y2k + 3 * fs, off);
+            double *uxo_k = xn + 2 * (size_t)k * fs;
 
             if (valid) {
-                xn[(size_t)(2 * k) * fs + e] = ux;
-                xn[(size_t)(2 * k + 1) * fs + e] = uy;
+                sto(uxo_k, off, ux);
+                sto(uxo_k + fs, off, uy);
                 // G*(-A'y_n): NNE/mean_zero_indicator.m:78-84
                 maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], wx);
                 maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], -wx);
@@ -218,21 +233,16 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_fused_tv(MfParams P, const doub
             const double e1 = fwd_diff(uxb, uxbj, uxbj, last_j, linear, P.inv_h2);
             const double e2 = fwd_diff(uyb, uybi, uybi, last_i, linear, P.inv_h1);
             const double e3 = fwd_diff(uyb, uybj, uybj, last_j, linear, P.inv_h2);
-            double s1v, s2v;
-            sv_2x2(d0, d1, d2, d3, s1v, s2v);
-            sums[DS_F2] += vmask * (s1v + s2v);                                // NNE/pointwise_2x2_nn.m:32
+            sums[DS_F2] += vmask * nuc_2x2(d0, d1, d2, d3);                    // NNE/pointwise_2x2_nn.m:32
             const double t0 = v0 + sigma * e0, t1 = v1 + sigma * e1, t2 = v2 + sigma * e2, t3 = v3 + sigma * e3;
-            double r0, r1, r2, r3;
-            svt_2x2(t0 * inv_sigma, t1 * inv_sigma, t2 * inv_sigma, t3 * inv_sigma, P.mu2 * inv_sigma, r0, r1, r2,
-                    r3);                                                       // :46-48
-            const double n0 = t0 - sigma * r0, n1 = t1 - sigma * r1, n2 = t2 - sigma * r2, n3 = t3 - sigma * r3;
-            sv_2x2(n0, n1, n2, n3, s1v, s2v);
+            double n0, n1, n2, n3, s1v;
+            proj_spectral_2x2(t0, t1, t2, t3, P.mu2, n0, n1, n2, n3, s1v);     // :46-48 (Moreau), :56
             if (valid) {
-                pout[(size_t)k * fs + e] = y1n;
-                double *o2 = pout + (size_t)(K + 4 * k) * fs + e;
-                o2[0] = n0; o2[(size_t)fs] = n1; o2[2 * (size_t)fs] = n2; o2[3 * (size_t)fs] = n3;
+                double *o1 = pout + (size_t)k * fs, *o2 = pout + ((size_t)K + 4 * (size_t)k) * fs;
+                sto(o1, off, y1n);
+                sto(o2, off, n0); sto(o2 + fs, off, n1); sto(o2 + 2 * fs, off, n2); sto(o2 + 3 * fs, off, n3);
                 maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], fabs(y1n));
-                maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], s1v);      // :56
+                maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], s1v);
             }
             sums[DS_UX] += vmask * ux;
             sums[DS_UY] += vmask * uy;
