@@ -22,6 +22,9 @@ static thread_local std::string g_err;
         return (code);                                       \
     } while (0)
 
+#define CP_FUSED_MAXGRID 4096
+#define CP_S1_GROUP 64
+
 #define CP_NOT_ITERATING(h) \
     if ((h)->it_n >= 0) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState an iteration is open: call cp_iterate_end / cp_mg_end first")
 
@@ -68,7 +71,7 @@ struct cp_engine {
     int hist_rows = 0;   // rows allocated (per problem)
     int hcols = 0;
     int nblk = 0;
-    int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU: two LDS tiles per wave)
+    int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU resident: two LDS tiles per wave)
     bool linearized = false, has_nu = false, has_images = false;
     hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless cp_set_stream)
     int it_n = -1;                     // >= 0 between cp_iterate_begin / cp_mg_begin and the matching end: iterations done
@@ -261,11 +264,16 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         HIPCHK(hipMalloc(&h->img, sizeof(double) * imgN));
         if (!mf && h->gt != GT_SAD_DEN) HIPCHK(hipMalloc(&h->imgR, sizeof(double) * imgN));
         h->nblk = grid_for(h);
-        h->nblk_fused = std::max(1, std::min((h->npix + CP_BLOCK - 1) / CP_BLOCK, 256 * 2));
+        // k_mf_fused_tv: up to 4096 workgroups (512 are resident: 2 per CU), chunks strided by the grid. Measured at
+        // 4096^2 x 16: 12.1 ms with 512 workgroups, 11.4 ms with 4096, 11.3 ms with one chunk per workgroup (65536).
+        h->nblk_fused = std::max(1, std::min((h->npix + CP_BLOCK - 1) / CP_BLOCK, CP_FUSED_MAXGRID));
+        if (const char *ev = getenv("CP_TUNE_FUSED_GRID"))   // tuning knob (benchmarks only), clamped to the buffer sizes
+            h->nblk_fused = std::max(1, std::min(h->nblk_fused, atoi(ev)));
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
             HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
             HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(h->nblk, h->nblk_fused) * CP_PSTRIDE));
+            HIPCHK(hipMalloc(&h->part2, sizeof(double) * (size_t)(CP_FUSED_MAXGRID / CP_S1_GROUP) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->svout, sizeof(double) * (16 + 256 + 256)));
             HIPCHK(hipMalloc(&h->red, sizeof(double) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->ctrl, sizeof(CpCtrl)));
@@ -565,6 +573,43 @@ static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int
     return CP_OK;
 }
 
+// First stage of the reduction of the fused kernel's partial rows: output row r = fixed-order sum (slots < CP_NSUM and
+// the Gram entries) / maximum (slots CP_NSUM..CP_NSCAL-1) of input rows [r*CP_S1_GROUP, (r+1)*CP_S1_GROUP).
+__global__ __launch_bounds__(256) void k_mf_reduce_stage1(int nrows, const double *__restrict__ part, double *__restrict__ out) {
+    const int r0 = blockIdx.x * CP_S1_GROUP, r1 = min(nrows, r0 + CP_S1_GROUP);
+    for (int c = threadIdx.x; c < CP_PSTRIDE; c += 256) {
+        const bool is_max = (c >= CP_NSUM && c < CP_NSCAL);
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = is_max ? -1.0e300 : 0.0;
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double o = part[(size_t)(r + u) * CP_PSTRIDE + c];
+                a[u] = is_max ? fmax(a[u], o) : a[u] + o;
+            }
+        }
+        for (int u = 0; r < r1; ++r, ++u) {
+            const double o = part[(size_t)r * CP_PSTRIDE + c];
+            a[u] = is_max ? fmax(a[u], o) : a[u] + o;
+        }
+        double v;
+        if (is_max) v = fmax(fmax(fmax(a[0], a[1]), fmax(a[2], a[3])), fmax(fmax(a[4], a[5]), fmax(a[6], a[7])));
+        else v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        out[(size_t)blockIdx.x * CP_PSTRIDE + c] = v;
+    }
+}
+
+// partial rows of the last k_mf_fused_tv launch as the single-workgroup kernels read them (after stage 1 if needed)
+static const double *fused_partials(cp_engine *h, int *rows) {
+    if (h->nblk_fused <= 512) { *rows = h->nblk_fused; return h->part; }
+    const int r2 = (h->nblk_fused + CP_S1_GROUP - 1) / CP_S1_GROUP;
+    hipLaunchKernelGGL(k_mf_reduce_stage1, dim3(r2), dim3(256), 0, h->stream, h->nblk_fused, h->part, h->part2);
+    *rows = r2;
+    return h->part2;
+}
+
 // ---- fused NN-TV path: F_0 = dual step 1 alone, then one k_mf_fused_tv + k_mf_efused per iteration -------------
 static int mf_fused_start(cp_engine *h, const MfParams &P, double tol) {
     CpCtrl *ctrl = (CpCtrl *)h->ctrl;
@@ -588,10 +633,11 @@ static int mf_fused_iterations(cp_engine *h, const MfParams &P, int n0, int coun
         }
         CPCHK(timer_end(h, T_DUAL));
         EFusedArgs A;
-        A.nblk = h->nblk_fused; A.K = h->K; A.n = n; A.check_stop = check; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
+        A.K = h->K; A.n = n; A.check_stop = check; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
         A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot;
         CPCHK(timer_begin(h, T_EIG));
-        hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, h->part, ctrl, h->W[nxt], h->hist_p,
+        const double *rows = fused_partials(h, &A.nblk);
+        hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, rows, ctrl, h->W[nxt], h->hist_p,
                            h->hist_d);
         CPCHK(timer_end(h, T_EIG));
     }
@@ -1132,7 +1178,9 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, h->X[prv], h->X[cur], h->P[cur],
                                h->P[nxt], h->g, h->b, h->W[cur], (const CpCtrl *)ctrl, h->part);
             CPCHK(timer_end(h, T_DUAL));
-            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk_fused, h->part, dev_buf);
+            int nrows = 0;
+            const double *rows = fused_partials(h, &nrows);
+            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, nrows, rows, dev_buf);
             break;
         }
         case CP_STAGE_EFUSED: {
