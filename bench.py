@@ -25,7 +25,27 @@ ELEMS_ITER = {"tv": 37, "curvature": 31}
 # dominant kernel: NN-TV runs one fused kernel per iteration (k_mf_fused_tv: the whole iteration's 37 elements);
 # NN-curvature runs separate passes, the dual pass (reads x(3)+x_old(3)+p(4)+grad(2)+b(1), writes p(4)) dominates
 ELEMS_DOM = {"tv": 37, "curvature": 17}
-DOM_KERNEL = {"tv": "k_mf_fused_tv<false,true>", "curvature": "k_mf_dual<0,1>"}
+DOM_KERNEL = {"tv": "k_mf_fused_tv<false,true,1>", "curvature": "k_mf_dual<0,1>"}
+
+
+def measured_copy_gbs(dev):
+    """device-to-device copy rate of this box (read + write bytes / time), the practical HBM ceiling next to the
+    vendor peak (SURVEY.md section 8d asks for both)"""
+    import torch
+    n = 1 << 28                                   # 2 GiB per buffer
+    a = torch.empty(n, dtype=torch.float64, device=dev)
+    b = torch.zeros(n, dtype=torch.float64, device=dev)
+    best = 0.0
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        a.copy_(b)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * 8.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return best
 
 
 def parse():
@@ -121,6 +141,8 @@ def main():
     est, n_power = solver.norm_estimate()
     tau = sigma = math.sqrt(0.99 / est ** 2)                   # :195-196
 
+    copy_gbs = measured_copy_gbs(dev) if rank == 0 else 0.0
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -187,6 +209,7 @@ def main():
                        "kernel_ms": {kname: (v[0] / max(v[1], 1)) for kname, v in times.items()}},
             "roofline": {"bound": "hbm", "kernel": DOM_KERNEL[reg], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
                          "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)"},
         }
         if not args.no_cpu_baseline:

@@ -71,6 +71,7 @@ struct cp_engine {
     int hist_rows = 0;   // rows allocated (per problem)
     int hcols = 0;
     int nblk = 0;
+    int fused_tw = 1;    // image columns per workgroup tile of k_mf_fused_tv
     int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU resident: two LDS tiles per wave)
     bool linearized = false, has_nu = false, has_images = false;
     hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless cp_set_stream)
@@ -266,9 +267,12 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         h->nblk = grid_for(h);
         // k_mf_fused_tv: up to 4096 workgroups (512 are resident: 2 per CU), chunks strided by the grid. Measured at
         // 4096^2 x 16: 12.1 ms with 512 workgroups, 11.4 ms with 4096, 11.3 ms with one chunk per workgroup (65536).
-        h->nblk_fused = std::max(1, std::min((h->npix + CP_BLOCK - 1) / CP_BLOCK, CP_FUSED_MAXGRID));
-        if (const char *ev = getenv("CP_TUNE_FUSED_GRID"))   // tuning knob (benchmarks only), clamped to the buffer sizes
-            h->nblk_fused = std::max(1, std::min(h->nblk_fused, atoi(ev)));
+        // tile width 1 (256 rows x 1 column) measured best at 4096^2 x 16: 11.6-11.9 ms vs 11.7 (2) and 12.0 (4); wider
+        // tiles turn the i+1 spill-over line of every wave into a miss of its own XCD's L2
+        h->fused_tw = 1;
+        if (const char *ev = getenv("CP_TUNE_FUSED_TW")) h->fused_tw = (atoi(ev) == 4) ? 4 : (atoi(ev) == 2 ? 2 : 1);   // tuning knobs
+        h->nblk_fused = std::max(1, std::min(fused_tiles(h->m, h->nl, h->fused_tw), CP_FUSED_MAXGRID));
+        if (const char *ev = getenv("CP_TUNE_FUSED_GRID")) h->nblk_fused = std::max(1, std::min(h->nblk_fused, atoi(ev)));
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
             HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
@@ -573,6 +577,17 @@ static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int
     return CP_OK;
 }
 
+typedef void (*fused_kernel_t)(MfParams, const double *, double *, const double *, double *, const double *, const double *,
+                               const double *, const CpCtrl *, double *);
+template <int TW>
+static fused_kernel_t fused_kernel_tw(const cp_engine *h) {
+    return (h->d.bc == CP_BC_LINEAR) ? (h->K == CP_KMAX ? k_mf_fused_tv<true, true, TW> : k_mf_fused_tv<true, false, TW>)
+                                     : (h->K == CP_KMAX ? k_mf_fused_tv<false, true, TW> : k_mf_fused_tv<false, false, TW>);
+}
+static fused_kernel_t fused_kernel(const cp_engine *h) {
+    return h->fused_tw == 1 ? fused_kernel_tw<1>(h) : (h->fused_tw == 2 ? fused_kernel_tw<2>(h) : fused_kernel_tw<4>(h));
+}
+
 // First stage of the reduction of the fused kernel's partial rows: output row r = fixed-order sum (slots < CP_NSUM and
 // the Gram entries) / maximum (slots CP_NSUM..CP_NSCAL-1) of input rows [r*CP_S1_GROUP, (r+1)*CP_S1_GROUP).
 __global__ __launch_bounds__(256) void k_mf_reduce_stage1(int nrows, const double *__restrict__ part, double *__restrict__ out) {
@@ -625,9 +640,7 @@ static int mf_fused_iterations(cp_engine *h, const MfParams &P, int n0, int coun
         const int cur = n & 1, prv = (n - 1) & 1, nxt = (n + 1) & 1;   // x_{n-1} in X[prv], y_n in P[cur]
         CPCHK(timer_begin(h, T_DUAL));
         {
-            auto kern = (h->d.bc == CP_BC_LINEAR)
-                            ? (h->K == CP_KMAX ? k_mf_fused_tv<true, true> : k_mf_fused_tv<true, false>)
-                            : (h->K == CP_KMAX ? k_mf_fused_tv<false, true> : k_mf_fused_tv<false, false>);
+            auto kern = fused_kernel(h);
             hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, h->X[prv], h->X[cur], h->P[cur],
                                h->P[nxt], h->g, h->b, h->W[cur], (const CpCtrl *)ctrl, h->part);
         }
@@ -1174,7 +1187,7 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             if (n + 2 > h->hist_rows) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg iteration %d beyond the history capacity", n);
             const int cur = n & 1, prv = (n - 1) & 1, nxt = (n + 1) & 1;
             CPCHK(timer_begin(h, T_DUAL));
-            auto kern = (h->K == CP_KMAX) ? k_mf_fused_tv<false, true> : k_mf_fused_tv<false, false>;
+            auto kern = fused_kernel(h);
             hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, h->X[prv], h->X[cur], h->P[cur],
                                h->P[nxt], h->g, h->b, h->W[cur], (const CpCtrl *)ctrl, h->part);
             CPCHK(timer_end(h, T_DUAL));

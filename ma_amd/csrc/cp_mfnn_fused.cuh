@@ -70,7 +70,12 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
     wy = -vuy;
 }
 
-template <bool LINEAR, bool FULLK>
+// Tiles: a workgroup handles TW adjacent image columns x 256/TW rows per step (TW = 4: one column segment of 64 rows per
+// wave). Wider tiles serve the j+1 neighbour loads of waves 0..TW-2 from the next wave's own loads, but make the i+1
+// spill-over line of every wave a miss in the XCD's L2; TW = 1 measured best (see cp_create).
+__host__ __device__ inline int fused_tiles(int m, int nl, int tw) { return ((m + CP_BLOCK / tw - 1) / (CP_BLOCK / tw)) * ((nl + tw - 1) / tw); }
+
+template <bool LINEAR, bool FULLK, int TW>
 __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const double *__restrict__ xo,
                                                              double *__restrict__ xn, const double *__restrict__ pin,
                                                              double *__restrict__ pout, const double *__restrict__ g,
@@ -103,13 +108,14 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
     maxs[DM_Y1 - CP_NSUM] = 0.0; maxs[DM_S1 - CP_NSUM] = 0.0; maxs[PM_VL - CP_NSUM] = 0.0;
     double4_t acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 
-    // 1-D decomposition into chunks of 256 consecutive pixels (column-major): measured faster than 64 x 4 tiles
-    // (12.9 vs 14.1 ms at 4096^2 x 16), the j+-1 neighbour loads are served by L2 / Infinity Cache
-    for (int base = blockIdx.x * CP_BLOCK; base < P.npix; base += gridDim.x * CP_BLOCK) {
-        const bool valid = (base + tid) < P.npix;
-        const int q = valid ? base + tid : P.npix - 1;   // lanes past the end redo the last pixel, nothing is stored
-        const int j = q / m, i = q - j * m;
-        const unsigned off = 8u * (unsigned)(q + m);     // byte offset of (i, j) inside a field (halo column first)
+    constexpr int TH = CP_BLOCK / TW;
+    const int tiles_i = (m + TH - 1) / TH, ntiles = tiles_i * ((P.nl + TW - 1) / TW);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tj = t / tiles_i, ti = t - tj * tiles_i;
+        const int ii = ti * TH + (tid % TH), jj = tj * TW + (tid / TH);
+        const bool valid = (ii < m) && (jj < P.nl);
+        const int i = min(ii, m - 1), j = min(jj, P.nl - 1);   // lanes past the end redo an edge pixel, nothing is stored
+        const unsigned off = 8u * (unsigned)((j + 1) * m + i);   // byte offset of (i, j) inside a field (halo column first)
         const int jg = P.j_off + j;
         const bool last_i = (i == m - 1), last_j = (jg == P.n_global - 1);
 
@@ -183,6 +189,16 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
         const PixOff p0 = {off, off - mb};
         const PixOff pi = {oi > 0 ? off + 8u : off - 8u, (oi > 0 ? off + 8u : off - 8u) - mb};
         const PixOff pj = {oj > 0 ? off + mb : off - mb, oj > 0 ? off : off - 2u * mb};
+#ifdef CP_EXP_NOJ
+        const PixOff pjx = p0;
+#else
+        const PixOff pjx = pj;
+#endif
+#ifdef CP_EXP_NOI
+        const PixOff pix = p0;
+#else
+        const PixOff pix = pi;
+#endif
         const double vmask = valid ? 1.0 : 0.0;
         for (int k = 0; k < K; ++k) {
             const double *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
@@ -190,8 +206,8 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
             const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
             double ux, uy, uxo_, uyo_, wx, wy, uxi, uyi, oi0, oi1, uxj, uyj, oj0, oj1, wd0, wd1;
             primal_u_at<LINEAR>(P, i, jg, p0, fsb, y1k, y2k, gxk, uxk, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
-            primal_u_at<LINEAR>(P, i + oi, jg, pi, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
-            primal_u_at<LINEAR>(P, i, jg + oj, pj, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
+            primal_u_at<LINEAR>(P, i + oi, jg, pix, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
+            primal_u_at<LINEAR>(P, i, jg + oj, pjx, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
             const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
             const double bb = ldo(b + (size_t)k * fs, off);
             const double y1 = ldo(y1k, off);

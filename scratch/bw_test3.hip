@@ -32,6 +32,30 @@ __global__ __launch_bounds__(256, MINW) void k_pat(int npix, int m, size_t fs, c
     }
     if (ballast[0] == 1.5) out[0] = 1.0;
 }
+template <int TW, int LDSKB, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_pat2d(int m, int n, size_t fs, const double* __restrict__ in, double* __restrict__ out) {
+    __shared__ double ballast[LDSKB * 128];
+    if (threadIdx.x == 0) ballast[0] = 0.0;
+    constexpr int TH = 256 / TW;
+    const int tiles_i = m / TH, ntiles = tiles_i * (n / TW);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int ti = t % tiles_i, tj = t / tiles_i;
+        const int i = ti * TH + (threadIdx.x % TH), j = tj * TW + (threadIdx.x / TH);
+        const unsigned off = 8u * (unsigned)((j + 1) * m + i);
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+            double v[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r] = *(const double*)((const char*)(in + (size_t)(r * K + k) * fs) + off);
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) s += v[r];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) *(double*)((char*)(out + (size_t)(w * K + k) * fs) + off) = s + w;
+        }
+    }
+    if (ballast[0] == 1.5) out[0] = 1.0;
+}
 int main() {
     const int m = 4096, n = 4096, npix = m * n;
     const size_t fs = (size_t)m * (n + 2);
@@ -49,9 +73,12 @@ int main() {
         printf("%-44s %.3f ms  %.0f GB/s\n", name, best, bytes / best / 1e6); fflush(stdout);
     };
 #define RUN(B, L, W, G) run("batch " #B " lds " #L "KB minw " #W " grid " #G, [&] { hipLaunchKernelGGL((k_pat<B, L, W>), dim3(G), dim3(256), 0, 0, npix, m, fs, (const double*)in, out); });
-    RUN(1, 70, 2, 512) RUN(1, 70, 2, 1024) RUN(1, 70, 2, 2048) RUN(1, 70, 2, 4096) RUN(1, 70, 2, 8192) RUN(1, 70, 2, 16384) RUN(1, 70, 2, 65536)
-    RUN(2, 70, 2, 4096) RUN(2, 70, 2, 65536)
-    RUN(1, 70, 2, 768) RUN(1, 70, 2, 1536) RUN(1, 70, 2, 520) RUN(1, 70, 2, 600)
+    RUN(1, 70, 2, 512) RUN(1, 70, 2, 4096) RUN(1, 70, 2, 65536)
+#define RUN2(TW, G) run("tile w" #TW " grid " #G, [&] { hipLaunchKernelGGL((k_pat2d<TW, 70, 2>), dim3(G), dim3(256), 0, 0, m, n, fs, (const double*)in, out); });
+    RUN2(1, 512) RUN2(1, 4096) RUN2(1, 65536)
+    RUN2(2, 512) RUN2(2, 4096) RUN2(2, 65536)
+    RUN2(4, 512) RUN2(4, 4096) RUN2(4, 65536)
+    RUN2(8, 4096) RUN2(8, 65536)
     CHK(hipDeviceSynchronize());
     return 0;
 }
