@@ -189,16 +189,6 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
         const PixOff p0 = {off, off - mb};
         const PixOff pi = {oi > 0 ? off + 8u : off - 8u, (oi > 0 ? off + 8u : off - 8u) - mb};
         const PixOff pj = {oj > 0 ? off + mb : off - mb, oj > 0 ? off : off - 2u * mb};
-#ifdef CP_EXP_NOJ
-        const PixOff pjx = p0;
-#else
-        const PixOff pjx = pj;
-#endif
-#ifdef CP_EXP_NOI
-        const PixOff pix = p0;
-#else
-        const PixOff pix = pi;
-#endif
         const double vmask = valid ? 1.0 : 0.0;
         for (int k = 0; k < K; ++k) {
             const double *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
@@ -206,8 +196,8 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
             const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
             double ux, uy, uxo_, uyo_, wx, wy, uxi, uyi, oi0, oi1, uxj, uyj, oj0, oj1, wd0, wd1;
             primal_u_at<LINEAR>(P, i, jg, p0, fsb, y1k, y2k, gxk, uxk, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
-            primal_u_at<LINEAR>(P, i + oi, jg, pix, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
-            primal_u_at<LINEAR>(P, i, jg + oj, pjx, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
+            primal_u_at<LINEAR>(P, i + oi, jg, pi, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
+            primal_u_at<LINEAR>(P, i, jg + oj, pj, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
             const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
             const double bb = ldo(b + (size_t)k * fs, off);
             const double y1 = ldo(y1k, off);

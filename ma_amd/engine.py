@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcpengine.so")
+LIB_PATH = os.environ.get("CP_ENGINE_LIB", os.path.join(_HERE, "libcpengine.so"))   # override: experiments only
 
 MODEL_TV_L1_DENOISE, MODEL_TV_L1_REG, MODEL_TV_L2_REG, MODEL_MF_NN_TV, MODEL_MF_NN_CURV = 1, 2, 3, 4, 5
 BC = {"neumann": 0, "linear": 1, "dirichlet": 2}
