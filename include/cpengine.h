@@ -39,7 +39,10 @@ enum {
     CP_MODEL_TV_L1_REG     = 2, /* F=TV_registration, G=SAD_registration  PDO/test_TV_L1_registration.m:84-85 */
     CP_MODEL_TV_L2_REG     = 3, /* F=TV_registration, G=SSD_registration  PDO/test_TV_L2_registration.m:84-85 */
     CP_MODEL_MF_NN_TV      = 4, /* NNE/mf_nn_tv_registration_no_ref_ml.m:183-203,235-346          */
-    CP_MODEL_MF_NN_CURV    = 5  /* NNE/mf_nn_curvature_registration_no_ref_ml.m:182-202,230-332   */
+    CP_MODEL_MF_NN_CURV    = 5, /* NNE/mf_nn_curvature_registration_no_ref_ml.m:182-202,230-332   */
+    CP_MODEL_VAR_TV        = 6, /* NNE/var_tv_registration_no_ref_ml.m:154-176,201-260: x = u (2K fields),
+                                   y = [y1 (K); y2 (4K)], histories have 6 columns, b is stored centred (B*b) */
+    CP_MODEL_VAR_CURV      = 7  /* NNE/var_curvature_registration_no_ref_ml.m:116-175,199-252: y2 has 2K fields */
 };
 
 /* boundary condition strings of the reference */

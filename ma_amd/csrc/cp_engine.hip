@@ -10,6 +10,7 @@
 
 #include "../../include/cpengine.h"
 #include "cp_mfnn_fused.cuh"
+#include "cp_var.cuh"
 #include "cp_pair.cuh"
 
 static thread_local std::string g_err;
@@ -53,7 +54,8 @@ struct PassTimer {
 
 struct cp_engine {
     cp_problem_desc d;
-    bool mf = false;     // mf_nn model
+    bool mf = false;     // multi-image model (mf_nn or var): K images, CpCtrl, MfParams
+    bool var = false;    // variance model (no L block, no nuclear norm): cp_var.cuh
     int reg = 0;         // mf: 0 tv, 1 curvature
     int gt = 0;          // pairwise: GT_*
     int nc = 1;          // pairwise: components of u
@@ -197,12 +199,13 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
     const cp_problem_desc &d = *desc;
     if (d.m < 2 || d.n < 2) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg image size %d x %d", d.m, d.n);
     if (!(d.h[0] > 0.0) || !(d.h[1] > 0.0)) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg grid spacing must be positive");
-    const bool mf = (d.model == CP_MODEL_MF_NN_TV || d.model == CP_MODEL_MF_NN_CURV);
+    const bool var = (d.model == CP_MODEL_VAR_TV || d.model == CP_MODEL_VAR_CURV);
+    const bool mf = (d.model == CP_MODEL_MF_NN_TV || d.model == CP_MODEL_MF_NN_CURV) || var;
     const bool pw = (d.model == CP_MODEL_TV_L1_DENOISE || d.model == CP_MODEL_TV_L1_REG || d.model == CP_MODEL_TV_L2_REG);
     if (!mf && !pw) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg unknown model %d", d.model);
     if (mf) {
         if (d.k < 1 || d.k > CP_KMAX) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported k = %d (1..%d)", d.k, CP_KMAX);
-        if (d.model == CP_MODEL_MF_NN_TV && d.bc != CP_BC_NEUMANN && d.bc != CP_BC_LINEAR)
+        if ((d.model == CP_MODEL_MF_NN_TV || d.model == CP_MODEL_VAR_TV) && d.bc != CP_BC_NEUMANN && d.bc != CP_BC_LINEAR)
             CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");   // finite_difference_operator.m:35
         if (d.bc < 0 || d.bc > 2) CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");
         if (d.batch > 1) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported batch > 1 for mf_nn models");
@@ -223,14 +226,22 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
     }
     if (pw && (h->d.n_global != d.n)) { delete h; CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported slabs for pairwise models"); }
     h->mf = mf;
+    h->var = var;
     h->m = d.m; h->nl = d.n; h->npix = d.m * d.n; h->fs = d.m * (d.n + 2);
     h->batch = h->d.batch;
     if (mf) {
         h->K = d.k;
-        h->reg = (d.model == CP_MODEL_MF_NN_TV) ? 0 : 1;
-        h->nxf = 3 * h->K;
-        h->npf = (h->reg == 0 ? 6 : 4) * h->K;
-        h->hcols = CP_HCOLS_MF;
+        h->reg = (d.model == CP_MODEL_MF_NN_TV || d.model == CP_MODEL_VAR_TV) ? 0 : 1;
+        if (var) {
+            h->nxf = 2 * h->K;                               // x = u only, NNE/var_tv...:102
+            h->npf = (h->reg == 0 ? 5 : 3) * h->K;           // :117, var_curvature...:116
+            h->hcols = CP_HCOLS_VAR;
+            h->has_nu = true;                                // no nuclear-norm ball in these models
+        } else {
+            h->nxf = 3 * h->K;
+            h->npf = (h->reg == 0 ? 6 : 4) * h->K;
+            h->hcols = CP_HCOLS_MF;
+        }
     } else {
         h->K = 1;
         h->gt = (d.model == CP_MODEL_TV_L1_REG) ? GT_SAD_REG : (d.model == CP_MODEL_TV_L2_REG ? GT_SSD_REG : GT_SAD_DEN);
@@ -386,6 +397,8 @@ extern "C" int cp_linearize(cp_handle h, const double *u0) {
         const long long tot = (long long)W.npix * h->K;
         const int grid = (int)((tot + CP_BLOCK - 1) / CP_BLOCK);
         hipLaunchKernelGGL(k_mf_warp, dim3(grid), dim3(CP_BLOCK), 0, h->stream, W, h->img, xsrc, h->Tu, h->g, h->b);
+        if (h->var)   // b <- B*b, NNE/var_tv_registration_no_ref_ml.m:153-154
+            hipLaunchKernelGGL(k_var_center_b, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, mf_params(h, 1.0, 1.0, 1.0), h->b);
     } else {
         PwWarpParams W;
         W.m = h->m; W.n = h->nl; W.npix = h->npix; W.fs = h->fs; W.nxf = h->nxf;
@@ -436,6 +449,7 @@ extern "C" int cp_singular_values(cp_handle h, int which, double *sv) {
         if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_singular_values(0) before cp_linearize");
         field = h->Tu;
     } else if (which == 1) {
+        if (h->var) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported the variance models have no L block");
         field = h->X[0] + (size_t)2 * h->K * h->fs;
     } else {
         CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg which = %d", which);
@@ -471,7 +485,7 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
     HIPCHK(hipMemsetAsync(xa, 0, sizeof(double) * h->xN, h->stream));
     HIPCHK(hipMemsetAsync(xb, 0, sizeof(double) * h->xN, h->stream));
     if (x0) CPCHK(upload_fields(h, xa, x0, h->nxf));
-    else hipLaunchKernelGGL(k_mf_hash_start, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa);
+    else hipLaunchKernelGGL(k_mf_hash_start, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->nxf, xa);
     // ||x0||
     std::vector<double> hp((size_t)h->nblk * CP_PSTRIDE);
     auto sumsq_partials = [&](double &out) -> int {
@@ -496,7 +510,13 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
     int i = 0;
     while (i < 2 || std::fabs(e[i - 1] - e[i - 2]) > tol * e[i - 1]) {   // :25
         ++i;
-        if (h->reg == 0) {
+        if (h->var && h->reg == 0) {
+            hipLaunchKernelGGL((k_var_applyA<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa, scale, h->g, yb);
+            hipLaunchKernelGGL((k_var_applyAT<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, yb, h->g, xb, h->part);
+        } else if (h->var) {
+            hipLaunchKernelGGL((k_var_applyA<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa, scale, h->g, yb);
+            hipLaunchKernelGGL((k_var_applyAT<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, yb, h->g, xb, h->part);
+        } else if (h->reg == 0) {
             hipLaunchKernelGGL((k_mf_applyA<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa, scale, h->g, yb);
             hipLaunchKernelGGL((k_mf_applyAT<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, yb, h->g, xb, h->part);
         } else {
@@ -678,6 +698,110 @@ static int mf_end(cp_engine *h, const MfParams &P, int iterations) {
     return CP_OK;
 }
 
+// ---- variance models (cp_var.cuh) -----------------------------------------------------------------------------
+template <int MODE>
+static void launch_var_dual(cp_engine *h, const MfParams &P, const double *xc, const double *xo, const double *pin,
+                            double *pout, int cc, int co) {
+    if (h->reg == 0)
+        hipLaunchKernelGGL((k_var_dual<MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout, h->g,
+                           h->b, (const CpCtrl *)h->ctrl, cc, co, h->part);
+    else
+        hipLaunchKernelGGL((k_var_dual<MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout, h->g,
+                           h->b, (const CpCtrl *)h->ctrl, cc, co, h->part);
+}
+template <int MODE>
+static void launch_var_primal(cp_engine *h, const MfParams &P, const double *xc, double *xn, const double *p, int cc) {
+    if (h->reg == 0)
+        hipLaunchKernelGGL((k_var_primal<MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g,
+                           (const CpCtrl *)h->ctrl, cc, h->part);
+    else
+        hipLaunchKernelGGL((k_var_primal<MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g,
+                           (const CpCtrl *)h->ctrl, cc, h->part);
+}
+static VarFinArgs var_fin_args(const cp_engine *h, const MfParams &P, int rp, int rd, int check, int update, int newbuf,
+                               double tol) {
+    VarFinArgs A;
+    A.nblk = h->nblk; A.reg = h->reg; A.rp = rp; A.rd = rd; A.check_stop = check; A.update = update; A.newbuf = newbuf;
+    A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2; A.Ntot = P.Ntot;
+    return A;
+}
+// iterations n = n0+1 .. n0+count of PDO/chambolle_pock.m:156-179 (state parity follows n)
+static int var_iterations(cp_engine *h, const MfParams &P, int n0, int count, int check, double tol) {
+    CpCtrl *ctrl = (CpCtrl *)h->ctrl;
+    for (int n = n0 + 1; n <= n0 + count; ++n) {
+        const int cur = (n - 1) & 1, nxt = n & 1;
+        CPCHK(timer_begin(h, T_DUAL));
+        launch_var_dual<0>(h, P, h->X[cur], h->X[nxt], h->P[cur], h->P[nxt], cur, nxt);
+        CPCHK(timer_end(h, T_DUAL));
+        CPCHK(timer_begin(h, T_EIG));
+        hipLaunchKernelGGL(k_var_fin_dual, dim3(1), dim3(256), 0, h->stream, var_fin_args(h, P, n - 1, n, check, 0, 0, tol),
+                           h->part, ctrl, h->hist_p, h->hist_d);
+        CPCHK(timer_end(h, T_EIG));
+        CPCHK(timer_begin(h, T_PRIMAL));
+        launch_var_primal<0>(h, P, h->X[cur], h->X[nxt], h->P[nxt], cur);
+        CPCHK(timer_end(h, T_PRIMAL));
+        CPCHK(timer_begin(h, T_FIN));
+        hipLaunchKernelGGL(k_var_fin_primal, dim3(1), dim3(256), 0, h->stream, var_fin_args(h, P, -1, n, 0, 1, nxt, tol),
+                           h->part, ctrl, h->hist_p, h->hist_d);
+        CPCHK(timer_end(h, T_FIN));
+    }
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+static int var_end(cp_engine *h, const MfParams &P, int iterations) {
+    const int fb = iterations & 1;
+    hipLaunchKernelGGL(k_var_materialize, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->npf, h->X[fb], h->X[0], h->P[fb],
+                       h->P[0], (const CpCtrl *)h->ctrl, fb);
+    hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1]);
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+static int solve_var(cp_engine *h, double theta, double tau, double sigma, int maxIter, double tol, cp_result *res) {
+    if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_solve before cp_linearize");
+    CPCHK(ensure_hist(h, maxIter + 2));
+    const MfParams P = mf_params(h, theta, tau, sigma);
+    CpCtrl *ctrl = (CpCtrl *)h->ctrl;
+    HIPCHK(hipMemsetAsync(h->hist_p, 0, sizeof(double) * (size_t)h->hist_rows * h->hcols, h->stream));
+    HIPCHK(hipMemsetAsync(h->hist_d, 0, sizeof(double) * (size_t)h->hist_rows * h->hcols, h->stream));
+    CPCHK(mf_begin(h));
+    // row 0: primal_objective(x0), dual_objective(y0)          chambolle_pock.m:89-106
+    launch_var_dual<1>(h, P, h->X[0], h->X[1], h->P[0], nullptr, 0, 1);
+    hipLaunchKernelGGL(k_var_fin_dual, dim3(1), dim3(256), 0, h->stream, var_fin_args(h, P, 0, 0, 0, 0, 0, tol), h->part, ctrl,
+                       h->hist_p, h->hist_d);
+    launch_var_primal<1>(h, P, h->X[0], nullptr, h->P[0], 0);
+    hipLaunchKernelGGL(k_var_fin_primal, dim3(1), dim3(256), 0, h->stream, var_fin_args(h, P, -1, 0, 0, 0, 0, tol), h->part,
+                       ctrl, h->hist_p, h->hist_d);
+    HIPCHK(hipGetLastError());
+    int done = 0, stopped = 0, stop_iter = -1;
+    while (done < maxIter && !stopped) {
+        const int cnt = std::min(32, maxIter - done);
+        CPCHK(var_iterations(h, P, done, cnt, 1, tol));
+        done += cnt;
+        int hdr[2];
+        HIPCHK(hipMemcpyAsync(hdr, ctrl, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        stopped = hdr[0];
+        stop_iter = hdr[1];
+    }
+    if (!stopped) {   // primal row maxIter trails the last primal pass by one kernel
+        const int cur = maxIter & 1;
+        launch_var_dual<1>(h, P, h->X[cur], h->X[cur ^ 1], h->P[cur], nullptr, cur, cur ^ 1);
+        hipLaunchKernelGGL(k_var_fin_dual, dim3(1), dim3(256), 0, h->stream, var_fin_args(h, P, maxIter, -1, 0, 0, 0, tol),
+                           h->part, ctrl, h->hist_p, h->hist_d);
+        HIPCHK(hipGetLastError());
+    }
+    const int iterations = stopped ? stop_iter : maxIter;
+    if (stopped) {
+        int zero = 0;
+        HIPCHK(hipMemcpyAsync(ctrl, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    CPCHK(var_end(h, P, iterations));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->last[0] = cp_result{iterations, stopped ? CP_STOP_TOLERANCE : CP_STOP_MAXITER, iterations + 1, h->hcols};
+    if (res) *res = h->last[0];
+    return CP_OK;
+}
+
 static int solve_mf(cp_engine *h, double theta, double tau, double sigma, int maxIter, double tol, cp_result *res) {
     if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_solve before cp_linearize");
     if (!h->has_nu) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_solve before cp_set_nu");
@@ -843,6 +967,7 @@ extern "C" int cp_solve(cp_handle h, double theta, double tau, double sigma, int
     if (!(tau > 0.0) || !(sigma > 0.0)) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg step sizes must be positive");
     HIPCHK(hipSetDevice(h->d.device));
     CP_NOT_ITERATING(h);
+    if (h->var) return solve_var(h, theta, tau, sigma, max_iter, tol, res);
     return h->mf ? solve_mf(h, theta, tau, sigma, max_iter, tol, res) : solve_pw(h, theta, tau, sigma, max_iter, tol, res);
 }
 
@@ -971,7 +1096,7 @@ extern "C" int cp_iterate_begin(cp_handle h, double theta, double tau, double si
     if (h->mf) {
         const MfParams P = mf_params(h, theta, tau, sigma);
         CPCHK(mf_begin(h));
-        if (h->reg == 0) CPCHK(mf_fused_start(h, P, 0.0));
+        if (h->reg == 0 && !h->var) CPCHK(mf_fused_start(h, P, 0.0));
     } else {
         HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(PwCtrl) * h->batch, h->stream));
         HIPCHK(hipMemcpyAsync(h->X[1], h->X[0], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));
@@ -992,7 +1117,8 @@ extern "C" int cp_iterate_steps(cp_handle h, int32_t iters) {
     HIPCHK(hipEventRecord(t.ev[t.used], h->stream));
     if (h->mf) {
         const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
-        if (h->reg == 0) CPCHK(mf_fused_iterations(h, P, h->it_n, iters, 0, 0.0));
+        if (h->var) CPCHK(var_iterations(h, P, h->it_n, iters, 0, 0.0));
+        else if (h->reg == 0) CPCHK(mf_fused_iterations(h, P, h->it_n, iters, 0, 0.0));
         else CPCHK(mf_iterations(h, P, h->it_n, iters, 0, 0.0));
     } else {
         const PwParams P = pw_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
@@ -1013,7 +1139,8 @@ extern "C" int cp_iterate_end(cp_handle h) {
     h->it_n = -1;
     if (h->mf) {
         const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
-        CPCHK(mf_end(h, P, iters));
+        if (h->var) CPCHK(var_end(h, P, iters));
+        else CPCHK(mf_end(h, P, iters));
     } else if (iters & 1) {
         HIPCHK(hipMemcpyAsync(h->X[0], h->X[1], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->P[0], h->P[1], sizeof(double) * h->pN, hipMemcpyDeviceToDevice, h->stream));
@@ -1150,7 +1277,7 @@ extern "C" int cp_mg_halo_unpack(cp_handle h, int buf, int sel, int side, const 
 }
 
 extern "C" int cp_mg_begin(cp_handle h, double theta, double tau, double sigma) {
-    if (!h || !h->mf || h->reg != 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_begin needs an NN-TV handle");
+    if (!h || !h->mf || h->var || h->reg != 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_begin needs an NN-TV handle");
     HIPCHK(hipSetDevice(h->d.device));
     CP_NOT_ITERATING(h);
     if (!h->linearized || !h->has_nu) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_begin before linearize / set_nu");
@@ -1164,7 +1291,7 @@ extern "C" int cp_mg_begin(cp_handle h, double theta, double tau, double sigma) 
 
 extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, int32_t world, double scale,
                            int32_t check_stop, double tol) {
-    if (!h || !h->mf || h->reg != 0 || !dev_buf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_stage");
+    if (!h || !h->mf || h->var || h->reg != 0 || !dev_buf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_stage");
     HIPCHK(hipSetDevice(h->d.device));
     const bool power = (stage == CP_STAGE_APPLY_A || stage == CP_STAGE_APPLY_AT);
     if (!power && !(h->it_n >= 0 && h->it_mg)) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_stage without cp_mg_begin");
@@ -1249,7 +1376,7 @@ extern "C" int cp_mg_stop_state(cp_handle h, int32_t *stopped, int32_t *stop_ite
 }
 
 extern "C" int cp_mg_gram(cp_handle h, int which, const double *V, double *gram) {
-    if (!h || !h->mf || !gram) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_gram");
+    if (!h || !h->mf || h->var || !gram) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_gram");
     HIPCHK(hipSetDevice(h->d.device));
     CP_NOT_ITERATING(h);
     const double *field = (which == 0) ? h->Tu : h->X[0] + (size_t)2 * h->K * h->fs;
@@ -1275,13 +1402,13 @@ extern "C" int cp_mg_gram(cp_handle h, int which, const double *V, double *gram)
 }
 
 extern "C" int cp_mg_power_start(cp_handle h, double *local_sumsq) {
-    if (!h || !h->mf || !local_sumsq) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_power_start");
+    if (!h || !h->mf || h->var || !local_sumsq) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_power_start");
     HIPCHK(hipSetDevice(h->d.device));
     CP_NOT_ITERATING(h);
     MfParams P = mf_params(h, 1.0, 1.0, 1.0);
     HIPCHK(hipMemsetAsync(h->X[1], 0, sizeof(double) * h->xN, h->stream));
     HIPCHK(hipMemsetAsync(h->xtmp, 0, sizeof(double) * h->xN, h->stream));
-    hipLaunchKernelGGL(k_mf_hash_start, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[1]);
+    hipLaunchKernelGGL(k_mf_hash_start, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->nxf, h->X[1]);
     hipLaunchKernelGGL(k_sumsq_fields, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, h->npix, h->m, h->fs, h->nxf, h->X[1],
                        h->part);
     HIPCHK(hipGetLastError());

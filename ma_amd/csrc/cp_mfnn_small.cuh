@@ -534,8 +534,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_applyAT(MfParams P, const doubl
 }
 
 // deterministic start vector of the power iteration (global MATLAB index -> hash)
-__global__ __launch_bounds__(CP_BLOCK) void k_mf_hash_start(MfParams P, double *__restrict__ x) {
-    const long long tot = (long long)P.npix * 3 * P.K;
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_hash_start(MfParams P, int nfields, double *__restrict__ x) {
+    const long long tot = (long long)P.npix * nfields;
     for (long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot;
          gid += (long long)gridDim.x * CP_BLOCK) {
         const int f = (int)(gid / P.npix), q = (int)(gid - (long long)f * P.npix);

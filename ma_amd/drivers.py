@@ -239,3 +239,66 @@ def mf_nn_curvature_registration_no_ref_ml(img, optPara, **kw):
     lev = len(u) - 1
     o = int(optPara["outerIter"][0 if lev == 0 else 1]) - 1
     return u[lev][o], L[lev][o].reshape(-1, order="F"), SV
+
+
+# ------------------------------------------------------------------------------------------------
+def _var_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True):
+    """NNE/var_tv_registration_no_ref_ml.m:40-197 (and var_curvature...): multi-level loop, outer linearisations,
+    power iteration, CP solve; everything but the loop control stays on the device."""
+    k = len(img)
+    img = [normalize(im) for im in img]
+    m, n = img[0].shape
+    omega = [0.0, float(m), 0.0, float(n)]
+    levels = num_levels(m, n)                                                           # (:58)
+    max_outer = int(max(optPara["outerIter"]))
+    u = [[None] * max_outer for _ in range(levels)]
+    model = E.MODEL_VAR_TV if reg == "tv" else E.MODEL_VAR_CURV
+    sizes = [(m, n)]
+    for _ in range(levels - 1):
+        sizes.insert(0, ((sizes[0][0] + 1) // 2, (sizes[0][1] + 1) // 2))
+    engines = []
+    try:
+        for (ml, nl) in sizes:
+            h_grid = ((omega[1] - omega[0]) / ml, (omega[3] - omega[2]) / nl)          # (:85)
+            engines.append(E.Engine(model, ml, nl, k=k, bc=optPara["bc"], h=h_grid, omega=omega, mu=optPara["mu"],
+                                    device=device))
+        engines[-1].set_images(np.concatenate([_vecF(im) for im in img]))
+        for lev in range(levels - 1, 0, -1):
+            engines[lev].downsample_to(engines[lev - 1])                                # (:71-74)
+        for lev in range(levels):
+            eng = engines[lev]
+            ml, nl = sizes[lev]
+            outerIter = int(optPara["outerIter"][0 if lev == 0 else 1])
+            if lev > 0:
+                eng.prolong_from(engines[lev - 1], 2.0)                                # 2 * kron(x, ones(2)) (:109-114)
+                engines[lev - 1].close()
+            for o in range(outerIter):
+                eng.linearize()                                                        # (:141-161), b centred
+                x0n = normest_x0(2 * k * ml * nl) if normest_x0 is not None else None
+                norm_A_est, n_power = eng.norm_estimate(x0n)                           # (:164-165)
+                tau = math.sqrt(0.99 / norm_A_est ** 2)                                # (:168-169)
+                sigma = math.sqrt(0.99 / norm_A_est ** 2)
+                res = eng.solve(optPara["theta"], tau, sigma, optPara["maxIter"], optPara["tol"])
+                last = (lev == levels - 1) and (o == outerIter - 1)
+                if download_all or last:
+                    u[lev][o] = eng.primal().reshape((ml * nl, 2, k), order="F")       # (:179-182)
+                if keep is not None:
+                    ph, dh = eng.history()
+                    keep[(lev, o)] = dict(tau=tau, sigma=sigma, norm_est=norm_A_est, n_power=n_power,
+                                          primal_history=ph, dual_history=dh, iterations=res.iterations,
+                                          stop_reason=res.stop_reason)
+        return u
+    finally:
+        for e in engines:
+            e.close()
+
+
+def var_tv_registration_no_ref_ml(img, optPara, **kw):
+    """u = var_tv_registration_no_ref_ml(img, optPara)   (NNE/var_tv_registration_no_ref_ml.m:7)"""
+    return _var_ml(img, optPara, "tv", **kw)
+
+
+def var_curvature_registration_no_ref_ml(img, optPara, **kw):
+    """u = var_curvature_registration_no_ref_ml(img, optPara)   (NNE/var_curvature_registration_no_ref_ml.m:7);
+    the Laplacian's boundary condition comes from optPara['bc'] (the reference omits the argument, :119)."""
+    return _var_ml(img, optPara, "curvature", **kw)

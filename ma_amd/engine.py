@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CP_ENGINE_LIB", os.path.join(_HERE, "libcpengine.so"))   # override: experiments only
 
 MODEL_TV_L1_DENOISE, MODEL_TV_L1_REG, MODEL_TV_L2_REG, MODEL_MF_NN_TV, MODEL_MF_NN_CURV = 1, 2, 3, 4, 5
+MODEL_VAR_TV, MODEL_VAR_CURV = 6, 7
 BC = {"neumann": 0, "linear": 1, "dirichlet": 2}
 STOP_MAXITER, STOP_TOLERANCE = 0, 1
 
@@ -136,8 +137,13 @@ class Engine:
         d.n_global, d.j_offset = n_global, j_offset
         self.desc = d
         self.model, self.m, self.n, self.k, self.batch = model, m, n, k, batch
-        self.mf = model in (MODEL_MF_NN_TV, MODEL_MF_NN_CURV)
-        if self.mf:
+        self.var = model in (MODEL_VAR_TV, MODEL_VAR_CURV)
+        self.mf = model in (MODEL_MF_NN_TV, MODEL_MF_NN_CURV) or self.var
+        if self.var:
+            self.nx = 2 * k * m * n
+            self.ny = (5 if model == MODEL_VAR_TV else 3) * k * m * n
+            self.cols = 6
+        elif self.mf:
             self.nx = 3 * k * m * n
             self.ny = (6 if model == MODEL_MF_NN_TV else 4) * k * m * n
             self.cols = 7

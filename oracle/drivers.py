@@ -221,3 +221,105 @@ def mf_nn_problem(ML_lev, u0, h_grid, omega, reg, bc):
     A = sp.bmat([[A1, sp.identity(kmn)], [A2, sp.csr_matrix((A2.shape[0], kmn))],
                  [sp.csr_matrix((kmn, 2 * kmn)), ops.mean_free_operator(m, n, k)]], format="csr")
     return A, b, T_u, gs
+
+
+# --------------------------------------------------------------------------
+# NNE/var_tv_registration_no_ref_ml.m / NNE/var_curvature_registration_no_ref_ml.m
+def var_F(y, b, k, h_grid, mu, sigma, conjugate_flag, nargout, reg):
+    """Local function F of the variance drivers (var_tv...:201-260; var_curvature...:199-252); `b` is the second
+    SSD argument as passed by the caller (the drivers pass -B*b, var_tv...:172)."""
+    ncomp = 5 if reg == "tv" else 3
+    mn = y.size // (ncomp * k)
+    y1 = y[: k * mn]
+    y2 = y[k * mn:]
+    hh = float(np.prod(h_grid))
+    if nargout == 3:
+        res3 = np.zeros(ncomp * k * mn)
+        res3[: k * mn] = px.SSD(y1, b, hh, sigma, conjugate_flag, 3)[2]
+        if reg == "tv":
+            Y2 = y2.reshape((4 * mn, k), order="F")
+            for j in range(k):
+                res3[k * mn + j * 4 * mn: k * mn + (j + 1) * 4 * mn] = \
+                    px.norm21(Y2[:, j], mu * hh, sigma, conjugate_flag, 3)[2]
+        else:
+            res3[k * mn:] = px.SSD(y2, np.zeros(2 * k * mn), mu * hh, sigma, conjugate_flag, 3)[2]
+        return None, None, res3
+    r1_F1, r2_F1, _ = px.SSD(y1, b, hh, sigma, conjugate_flag, 2)
+    if reg == "tv":
+        Y2 = y2.reshape((4 * mn, k), order="F")
+        r1_F2, r2_F2 = 0.0, 0.0
+        for j in range(k):
+            a, c, _ = px.norm21(Y2[:, j], mu * hh, sigma, conjugate_flag, 2)
+            r1_F2 = r1_F2 + a
+            r2_F2 = max(r2_F2, c)
+    else:
+        r1_F2, r2_F2, _ = px.SSD(y2, np.zeros(2 * k * mn), mu * hh, sigma, conjugate_flag, 2)
+    return np.array([r1_F1, r1_F2]), max(r2_F1, r2_F2), None
+
+
+def var_problem(ML_lev, u0, h_grid, omega, reg, bc):
+    """(A, b_centred, T_u, g) for one linearisation: var_tv...:140-161 (A = [B*blkdiag(dT); D | Lap], b <- B*b)."""
+    k = len(ML_lev)
+    m, n = ML_lev[0].shape
+    kmn = k * m * n
+    b = np.zeros(kmn)
+    T_u = np.zeros((m, n, k))
+    dT, gs = [], []
+    for i in range(k):
+        T_u[:, :, i], g = ops.evaluate_displacement(ML_lev[i], h_grid, u0[:, :, i], omega)
+        gs.append(g)
+        dT.append(ops.grad_matrix(g))
+        b[i * m * n: (i + 1) * m * n] = T_u[:, :, i].reshape(-1, order="F") - dT[i] @ u0[:, :, i].reshape(-1, order="F")
+    Kc = ops.mean_free_operator(m, n, k)
+    b = Kc @ b                                                                   # (:154)
+    A1 = Kc @ sp.block_diag(dT, format="csr")                                    # (:157)
+    if reg == "tv":
+        A2 = ops.finite_difference_operator(m, n, h_grid, k, bc)                 # (:120)
+    else:
+        A2 = ops.discrete_laplacian(m, n, h_grid, k, bc)                         # var_curvature...:119 (bc: see driver)
+    return sp.vstack([A1, A2], format="csr"), b, T_u, gs
+
+
+def var_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start, keep=None):
+    """u = var_{tv,curvature}_registration_no_ref_ml(img, optPara)  (var_tv...:7-197).
+
+    Quirks kept: the prolongation multiplies by 2 (:112). NNE/var_curvature...:119 calls discrete_laplacian without
+    `bc` (an error in MATLAB as shipped); here optPara['bc'] is used for both regularisers."""
+    k = len(img)
+    img = [normalize(im) for im in img]
+    m, n = img[0].shape
+    omega = [0.0, float(m), 0.0, float(n)]
+    numLevels = ops.num_levels(m, n)
+    max_outer = int(max(optPara["outerIter"]))
+    u = [[None] * max_outer for _ in range(numLevels)]
+    ML = [ops.pyramid(im, numLevels) for im in img]
+    ncomp = 5 if reg == "tv" else 3
+    x = None
+    for lev in range(numLevels):
+        m, n = ML[0][lev].shape
+        h_grid = np.array([(omega[1] - omega[0]) / m, (omega[3] - omega[2]) / n])
+        theta, tol, mu, bc, maxIter = optPara["theta"], optPara["tol"], optPara["mu"], optPara["bc"], optPara["maxIter"]
+        outerIter = int(optPara["outerIter"][0 if lev == 0 else 1])
+        if lev == 0:
+            x = np.zeros(2 * k * m * n)
+        else:
+            m_low, n_low = ML[0][lev - 1].shape
+            x = ops.prolong_fields(x, m_low, n_low, m, n, 2 * k, factor=2.0)     # (:109-114)
+        p = np.zeros(ncomp * k * m * n)
+        s = (m, n, k)
+        Gh = lambda xx, c, nargout: px.mean_zero_indicator(xx, s, c, nargout)    # (:126)
+        u0 = x.reshape((m * n, 2, k), order="F")
+        for o in range(outerIter):
+            A, b, _, _ = var_problem([ML[i][lev] for i in range(k)], u0, h_grid, omega, reg, bc)
+            e = ops.matrix_norm(A, normest_x0(A.shape[1]) if normest_x0 is not None else None)
+            norm_A_est = e[-1]
+            tau = np.sqrt(0.99 / norm_A_est ** 2)                                # (:168-169)
+            sigma = np.sqrt(0.99 / norm_A_est ** 2)
+            Fh = lambda y, c, nargout, b_=b, sg=sigma: var_F(y, -b_, k, h_grid, mu, sg, c, nargout, reg)   # (:172)
+            x, p, ph, dh = chambolle_pock(Fh, Gh, A, x, p, theta, tau, sigma, maxIter, tol)
+            u0 = x.reshape((m * n, 2, k), order="F")
+            u[lev][o] = u0.copy()
+            if keep is not None:
+                keep[(lev, o)] = dict(tau=tau, sigma=sigma, norm_est=norm_A_est, n_power=len(e), primal_history=ph,
+                                      dual_history=dh, p=p.copy(), x=x.copy(), b=b.copy(), m=m, n=n)
+    return u

@@ -224,6 +224,29 @@ def mfnn_e2e():
     np.savez_compressed(os.path.join(HERE, "mfnn_e2e.npz"), **out)
 
 
+def var_e2e():
+    """variance drivers (NNE/var_{tv,curvature}_registration_no_ref_ml.m) on the frames of mfnn_e2e.npz"""
+    out = {}
+    m, n, k = 64, 64, 4
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    for reg, bc, mu in (("tv", "neumann", 0.1), ("curvature", "neumann", 5.0)):
+        opt = dict(theta=1.0, maxIter=60, tol=1e-3, outerIter=[3, 2], mu=mu, bc=bc)
+        keep = {}
+        u = od.var_registration_no_ref_ml([imgs[i] for i in range(k)], opt, reg, keep=keep)
+        out[f"{reg}_levels"] = np.array([len(u)])
+        for lev in range(len(u)):
+            for o in range(len(u[lev])):
+                if u[lev][o] is None:
+                    continue
+                kk = keep[(lev, o)]
+                out[f"{reg}_u_{lev}_{o}"] = u[lev][o]
+                out[f"{reg}_sched_{lev}_{o}"] = np.array([kk["tau"], kk["norm_est"], kk["n_power"],
+                                                          kk["primal_history"].shape[0]])
+                out[f"{reg}_ph_{lev}_{o}"] = kk["primal_history"]
+                out[f"{reg}_dh_{lev}_{o}"] = kk["dual_history"]
+    np.savez_compressed(os.path.join(HERE, "var_e2e.npz"), **out)
+
+
 if __name__ == "__main__":
     png = data_png()
     operators_fixture()
@@ -231,5 +254,6 @@ if __name__ == "__main__":
     pyramid_fixture()
     pairwise_e2e(png)
     mfnn_e2e()
+    var_e2e()
     for f in sorted(glob.glob(os.path.join(HERE, "*.npz"))):
         print(os.path.basename(f), os.path.getsize(f) // 1024, "KiB")

@@ -138,3 +138,29 @@ def test_mfnn_driver_fixture(golden_dir, reg, bc, mu):
             np.testing.assert_allclose(kk["dual_history"][:, :5], f[f"{reg}_dh_{lev}_{o}"][:, :5], rtol=1e-8, atol=1e-9)
             assert _rel(u[lev][o], f[key]) < 1e-9, (lev, o)
             assert _rel(L[lev][o], f[f"{reg}_L_{lev}_{o}"]) < 1e-9, (lev, o)
+
+
+@pytest.mark.parametrize("reg,bc,mu", [("tv", "neumann", 0.1), ("curvature", "neumann", 5.0)])
+def test_var_driver_fixture(golden_dir, reg, bc, mu):
+    """NNE/var_{tv,curvature}_registration_no_ref_ml.m end to end (2 levels, x2 prolongation) against the stored run"""
+    from ma_amd import drivers as D
+    f = _load(golden_dir, "var_e2e.npz")
+    imgs = _load(golden_dir, "mfnn_e2e.npz")["imgs"]
+    k = imgs.shape[0]
+    opt = dict(theta=1.0, maxIter=60, tol=1e-3, outerIter=[3, 2], mu=mu, bc=bc)
+    keep = {}
+    u = D._var_ml([imgs[i] for i in range(k)], opt, reg, keep=keep)
+    assert len(u) == int(f[f"{reg}_levels"][0])
+    for lev in range(len(u)):
+        for o in range(len(u[lev])):
+            key = f"{reg}_u_{lev}_{o}"
+            if key not in f:
+                assert u[lev][o] is None
+                continue
+            tau, norm_est, n_power, rows = f[f"{reg}_sched_{lev}_{o}"]
+            kk = keep[(lev, o)]
+            assert abs(kk["norm_est"] - norm_est) <= 1e-11 * norm_est and kk["n_power"] == int(n_power)
+            assert kk["primal_history"].shape[0] == int(rows)
+            np.testing.assert_allclose(kk["primal_history"], f[f"{reg}_ph_{lev}_{o}"], rtol=1e-8, atol=1e-9)
+            np.testing.assert_allclose(kk["dual_history"], f[f"{reg}_dh_{lev}_{o}"], rtol=1e-8, atol=1e-9)
+            assert _rel(u[lev][o], f[key]) < 1e-9, (lev, o)

@@ -1,0 +1,108 @@
+"""GPU parity of the variance models (NNE/var_tv_registration_no_ref_ml.m, NNE/var_curvature_registration_no_ref_ml.m):
+HIP engine through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300)
+
+
+@pytest.mark.parametrize("reg,bc,m,n,k,mu", [("tv", "neumann", 48, 40, 3, 0.1), ("tv", "linear", 33, 50, 4, 0.1),
+                                             ("curvature", "dirichlet", 40, 36, 3, 5.0),
+                                             ("curvature", "neumann", 70, 55, 5, 5.0), ("tv", "neumann", 64, 64, 16, 0.1)])
+def test_var_solve_matches_oracle(reg, bc, m, n, k, mu):
+    from ma_amd import engine as E, synth
+    from oracle import drivers as od, prox as px
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    u0 = synth.smooth_displacement(m, n, k, amp=1.5).numpy().reshape(k, 2, n * m)
+    u0_ref = np.transpose(u0, (2, 1, 0))
+    omega = [0.0, float(m), 0.0, float(n)]
+    h = (1.0, 1.0)
+    A, b, T_u, gs = od.var_problem([imgs[i] for i in range(k)], u0_ref, h, omega, reg, bc)
+    tau = sigma = 0.25 if reg == "tv" else 0.1
+    kmn = k * m * n
+    ncomp = 5 if reg == "tv" else 3
+    rng = np.random.default_rng(7)
+    x0 = u0.reshape(-1)
+    y0 = 0.01 * rng.standard_normal(ncomp * kmn)
+    Fh = lambda y, c, nargout: od.var_F(y, -b, k, h, mu, sigma, c, nargout, reg)
+    Gh = lambda x, c, nargout: px.mean_zero_indicator(x, (m, n, k), c, nargout)
+    iters = 20
+    xr, yr, phr, dhr = cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, sigma, iters, 1e-3)
+
+    eng = E.Engine(E.MODEL_VAR_TV if reg == "tv" else E.MODEL_VAR_CURV, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu)
+    eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+    eng.set_primal(x0)
+    eng.linearize()
+    _, _, bg = eng.get_linearization()
+    assert _rel(bg, b) < 1e-13                     # stored centred: B*b
+    eng.set_dual(y0)
+    est, npow = eng.norm_estimate(od.normest_start(2 * kmn))
+    from oracle import operators as oo
+    e_ref = oo.matrix_norm(A, od.normest_start(2 * kmn))
+    assert npow == len(e_ref) and abs(est - e_ref[-1]) <= 1e-11 * e_ref[-1]
+    eng.solve(1.0, tau, sigma, iters, 1e-3)
+    x, y = eng.primal(), eng.dual()
+    ph, dh = eng.history()
+    eng.close()
+    assert ph.shape == phr.shape and dh.shape == dhr.shape and ph.shape[1] == 6
+    np.testing.assert_allclose(ph, phr, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(dh, dhr, rtol=1e-9, atol=1e-10)
+    assert _rel(x, xr) < TOL and _rel(y, yr) < TOL
+
+
+@pytest.mark.parametrize("reg,bc,mu", [("tv", "neumann", 0.1), ("curvature", "neumann", 5.0)])
+def test_var_ml_driver(reg, bc, mu):
+    """multi-level driver end to end: x2 prolongation, outer re-linearisation, power iteration, stop rule"""
+    from ma_amd import drivers as D, synth
+    from oracle import drivers as od
+    m, n, k = 70, 66, 4
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    opt = dict(theta=1.0, maxIter=40, tol=1e-3, outerIter=[3, 2], mu=mu, bc=bc)
+    keep_r, keep_g = {}, {}
+    ur = od.var_registration_no_ref_ml([imgs[i] for i in range(k)], opt, reg, keep=keep_r)
+    ug = D._var_ml([imgs[i] for i in range(k)], opt, reg, normest_x0=od.normest_start, keep=keep_g)
+    assert set(keep_r) == set(keep_g)
+    for key in sorted(keep_r):
+        a, b = keep_g[key], keep_r[key]
+        assert abs(a["norm_est"] - b["norm_est"]) <= 1e-11 * b["norm_est"] and a["n_power"] == b["n_power"]
+        assert a["primal_history"].shape == b["primal_history"].shape
+        np.testing.assert_allclose(a["primal_history"], b["primal_history"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(a["dual_history"], b["dual_history"], rtol=1e-8, atol=1e-9)
+    for lev in range(len(ur)):
+        for o in range(len(ur[lev])):
+            if ur[lev][o] is None:
+                assert ug[lev][o] is None
+                continue
+            assert _rel(ug[lev][o], ur[lev][o]) < 1e-9, (lev, o)
+
+
+def test_var_iterate_in_parts():
+    from ma_amd import engine as E, synth
+    m, n, k = 40, 36, 4
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    u0 = synth.smooth_displacement(m, n, k, amp=1.5).numpy().reshape(-1)
+    out = []
+    for parts in (None, (3, 6)):
+        eng = E.Engine(E.MODEL_VAR_TV, m, n, k=k, bc="neumann", omega=[0.0, float(m), 0.0, float(n)], mu=0.1)
+        eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+        eng.set_primal(u0)
+        eng.linearize()
+        if parts is None:
+            eng.iterate(1.0, 0.2, 0.2, 9)
+        else:
+            eng.iterate_begin(1.0, 0.2, 0.2, 9)
+            eng.iterate_steps(parts[0])
+            eng.iterate_steps(parts[1])
+            eng.iterate_end()
+        eng.sync()
+        out.append((eng.primal(), eng.dual()))
+        with pytest.raises(E.CpEngineError):
+            eng.singular_values(1)
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

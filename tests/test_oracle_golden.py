@@ -54,3 +54,15 @@ def test_pairwise_first_step_fixture(golden_dir):
     u, v, hist, _ = od.tv_registration(R, T, lam, tau, int(iters), 1, "SAD", keep_histories=True)
     assert np.allclose(u, f["tvl1_rect_s0_u"], atol=1e-12)
     assert np.allclose(hist[0][0], f["tvl1_rect_s0_ph"], rtol=1e-12, atol=1e-12)
+
+
+def test_var_driver_fixture(golden_dir):
+    """variance driver: the first outer iteration of the coarsest level reproduces the stored run"""
+    f = _load(golden_dir, "var_e2e.npz")
+    imgs = _load(golden_dir, "mfnn_e2e.npz")["imgs"]
+    k = imgs.shape[0]
+    opt = dict(theta=1.0, maxIter=60, tol=1e-3, outerIter=[1, 1], mu=0.1, bc="neumann")
+    keep = {}
+    od.var_registration_no_ref_ml([imgs[i] for i in range(k)], opt, "tv", keep=keep)
+    assert np.allclose(keep[(0, 0)]["primal_history"], f["tv_ph_0_0"], rtol=1e-12, atol=1e-12)
+    assert abs(keep[(0, 0)]["norm_est"] - f["tv_sched_0_0"][1]) <= 1e-13 * f["tv_sched_0_0"][1]
