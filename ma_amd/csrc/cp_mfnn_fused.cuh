@@ -270,14 +270,34 @@ struct EFusedArgs {
 __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, const double *__restrict__ part,
                                                               CpCtrl *ctrl, double *__restrict__ Wout, double *hist_p,
                                                               double *hist_d) {
-    __shared__ double G[16][17], V[16][17], G2[16][17], sc[CP_NSCAL], cs[8][2], dvec[16], stage[CP_RED_THREADS];
-    __shared__ int pq[8][2], rotflag;
+    __shared__ double G[16][17], V[16][17], G2[16][17], G2h[16][17], sc[CP_NSCAL], cs[2][8][2], dvec[16],
+        stage[CP_RED_THREADS];
+    __shared__ int pq[2][8][2], rotflag[2];
     __shared__ double res[4];   // spmax, con3
     if (ctrl->stop) return;
     const int t = threadIdx.x;
     reduce_partials(part + 256, A.nblk, G2, sc, stage);   // Gram(B*L_n)   (second Gram block)
     reduce_partials(part, A.nblk, G, sc, stage);          // Gram(y3~_{n+1}) and the scalars
-    jacobi16<true>(G, V, cs, pq, &rotflag);
+    if (t < 256) {   // Gram(B*L_n) restricted to the complement of (1,..,1) (see k_mf_fin)
+        const int a = t >> 4, bq = t & 15, K = A.K;
+        double acc = 0.0;
+        if (a < K - 1 && bq < K - 1) {
+            const double na = 1.0 / sqrt((double)(a + 1) * (a + 2)), nb = 1.0 / sqrt((double)(bq + 1) * (bq + 2));
+            for (int i = 0; i <= a + 1; ++i) {
+                const double qa = (i <= a) ? na : -(double)(a + 1) * na;
+                double row = 0.0;
+                for (int j = 0; j <= bq + 1; ++j) {
+                    const double qb = (j <= bq) ? nb : -(double)(bq + 1) * nb;
+                    row += G2[i][j] * qb;
+                }
+                acc += qa * row;
+            }
+        }
+        G2h[a][bq] = acc;
+    }
+    if (t >= 512) return;        // the eigensolves need 2 x 256 threads; ended waves do not take part in barriers
+    __syncthreads();
+    jacobi16_pair(G, V, G2h, cs, pq, rotflag);
     if (t == 0) {
         const int K = A.K;
         const double nu = ctrl->nu, mu_ = nu * A.sigma;   // NNE/nuclear_norm_constraint.m:72
@@ -324,32 +344,12 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
         for (int i = 0; i < 16; ++i) a -= V[k][i] * dvec[i] * V[kp][i];
         Wout[k * CP_KMAX + kp] = a;
     }
-    {   // Gram(B*L_n) restricted to the complement of (1,..,1) (see k_mf_fin), then eigenvalues
-        const int a = (t >> 4) & 15, bq = t & 15, K = A.K;
-        double acc = 0.0;
-        if (t < 256 && a < K - 1 && bq < K - 1) {
-            const double na = 1.0 / sqrt((double)(a + 1) * (a + 2)), nb = 1.0 / sqrt((double)(bq + 1) * (bq + 2));
-            for (int i = 0; i <= a + 1; ++i) {
-                const double qa = (i <= a) ? na : -(double)(a + 1) * na;
-                double row = 0.0;
-                for (int j = 0; j <= bq + 1; ++j) {
-                    const double qb = (j <= bq) ? nb : -(double)(bq + 1) * nb;
-                    row += G2[i][j] * qb;
-                }
-                acc += qa * row;
-            }
-        }
-        __syncthreads();
-        if (t < 256) G[a][bq] = acc;
-        __syncthreads();
-    }
-    jacobi16<false>(G, nullptr, cs, pq, &rotflag);
     if (t == 0) {
         const double nu = ctrl->nu;
         double sumS = 0.0;
         for (int i = 0; i < A.K; ++i) ctrl->svL[i] = 0.0;
         for (int i = 0; i < A.K - 1; ++i) {
-            const double s = sqrt(fmax(G[i][i], 0.0));
+            const double s = sqrt(fmax(G2h[i][i], 0.0));
             ctrl->svL[i] = s;
             sumS += s;
         }
