@@ -158,7 +158,13 @@ __device__ __forceinline__ double ldo(const double *__restrict__ ubase, unsigned
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(ubase) + (size_t)off + (ptrdiff_t)delta);
 }
 __device__ __forceinline__ void sto(double *__restrict__ ubase, unsigned off, double v) {
-    *reinterpret_cast<double *>(reinterpret_cast<char *>(ubase) + (size_t)off) = v;
+    // streaming store: results are not read again by the launch that writes them, so they should not displace the
+    // neighbour lines other workgroups are about to re-read from L2 (measured: -2 GB fetched, -1.5..3 % time)
+    __builtin_nontemporal_store(v, reinterpret_cast<double *>(reinterpret_cast<char *>(ubase) + (size_t)off));
+}
+// single-use streams (read by exactly one thread of the launch)
+__device__ __forceinline__ double ldo_stream(const double *__restrict__ ubase, unsigned off) {
+    return __builtin_nontemporal_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(ubase) + (size_t)off));
 }
 
 // sqrt(x) and 1/sqrt(x) from one v_rsq_f64 and the Goldschmidt / residual steps of the compiler's own f64 sqrt

@@ -127,9 +127,9 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
 #pragma unroll
             for (int k = 0; k < CP_KMAX; ++k) {
                 const int kk = (FULLK || k < K) ? k : K - 1;
-                t3[k] = ldo(y3in + (size_t)kk * fs, off);
+                t3[k] = ldo_stream(y3in + (size_t)kk * fs, off);
                 y1v[k] = ldo(pin + (size_t)kk * fs, off);
-                Lr[k] = ldo(Lin + (size_t)kk * fs, off);
+                Lr[k] = ldo_stream(Lin + (size_t)kk * fs, off);
             }
 #pragma unroll
             for (int kp = 0; kp < CP_KMAX; ++kp) a[kp] = 0.0;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
             primal_u_at<LINEAR>(P, i + oi, jg, pi, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
             primal_u_at<LINEAR>(P, i, jg + oj, pj, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
             const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
-            const double bb = ldo(b + (size_t)k * fs, off);
+            const double bb = ldo_stream(b + (size_t)k * fs, off);
             const double y1 = ldo(y1k, off);
             const double v0 = ldo(y2k, off), v1 = ldo(y2k + fs, off), v2 = ldo(y2k + 2 * fs, off), v3 = ldo(y2k + 3 * fs, off);
             double *uxo_k = xn + 2 * (size_t)k * fs;
