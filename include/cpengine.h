@@ -64,6 +64,11 @@ enum {
     CP_ERR_UNSUPPORTED = 5   /* cpengine:unsupported */
 };
 
+/* CP_FLAG_VAR_SSD_SWAP: the single-level driver NNE/var_tv_registration_no_ref.m:173 calls the prox of the data
+ * term as SSD(y1, b, sigma, 1, flag) (lambda and tau exchanged) while its value calls (:192) use (1, sigma); set
+ * this flag to reproduce that driver, leave it clear for the *_ml drivers. */
+enum cp_flag { CP_FLAG_VAR_SSD_SWAP = 1 };
+
 typedef struct cp_problem_desc {
     int32_t model;      /* CP_MODEL_*                                                        */
     int32_t m, n;       /* image rows, columns (column-major, rows contiguous)               */
@@ -71,7 +76,7 @@ typedef struct cp_problem_desc {
     int32_t bc;         /* CP_BC_* ; pairwise models always use neumann (script form)        */
     int32_t device;     /* HIP device ordinal                                                */
     int32_t batch;      /* number of independent problems of this shape in the handle (>=1)  */
-    int32_t reserved0;
+    int32_t flags;      /* CP_FLAG_* (0 for the reference's current drivers)                 */
     double  h[2];       /* grid spacing h_grid = [h1, h2]                                    */
     double  omega[4];   /* image region [w1,w2]x[w3,w4]; all zeros -> [0, m*h1, 0, n*h2]     */
     double  lambda;     /* data-term weight of the pairwise models                           */

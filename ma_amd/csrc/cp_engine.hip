@@ -96,6 +96,7 @@ static MfParams mf_params(const cp_engine *h, double theta, double tau, double s
     P.mu1 = h->d.h[0] * h->d.h[1];              // prod(h_grid), NNE/mf_nn_tv...:257
     P.mu2 = h->d.mu * (h->d.h[0] * h->d.h[1]);  // mu * prod(h_grid), :264
     P.sigma = sigma; P.tau = tau; P.theta = theta;
+    P.ssd_swap = (h->d.flags & CP_FLAG_VAR_SSD_SWAP) ? 1 : 0;
     P.invK = 1.0 / (double)h->K;
     P.Ntot = (double)h->m * (double)h->d.n_global * (double)h->K;
     return P;

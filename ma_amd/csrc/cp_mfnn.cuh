@@ -37,6 +37,7 @@ struct MfParams {
     int n_global, j_off;
     int bc;
     int fs;
+    int ssd_swap;             // CP_FLAG_VAR_SSD_SWAP (variance models only)
     double inv_h1, inv_h2;
     double mu1, mu2;          // h1*h2, mu*h1*h2
     double sigma, tau, theta;

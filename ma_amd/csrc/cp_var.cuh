@@ -116,8 +116,12 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
             if (MODE == 0) {
                 const double yt = y1 + sigma * a_bar;
                 // NNE/SSD.m:60-61 with :43 (tau -> 1/tau): x - tau*((x/tau + (lambda/tau) g)/(1 + lambda/tau))
-                const double lt = P.mu1 * inv_sigma;
-                y1n = yt - sigma * ((yt * inv_sigma + lt * gg) / (1.0 + lt));
+                if (P.ssd_swap) {   // NNE/var_tv_registration_no_ref.m:173: SSD(y1, b, sigma, 1, flag) -> lambda = sigma, tau = 1
+                    y1n = yt - (yt + sigma * gg) / (1.0 + sigma);
+                } else {
+                    const double lt = P.mu1 * inv_sigma;
+                    y1n = yt - sigma * ((yt * inv_sigma + lt * gg) / (1.0 + lt));
+                }
                 pout[(size_t)k * fs + e] = y1n;
             } else {
                 y1n = y1;

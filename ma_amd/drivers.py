@@ -160,12 +160,16 @@ def num_levels(m, n):
     return int(min(math.floor(math.log2(m) - 5), math.floor(math.log2(n) - 5))) + 1   # mf_nn_tv...:59
 
 
-def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True):
+def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True, single_level=False):
     k = len(img)
     img = [normalize(im) for im in img]
     m, n = img[0].shape
     omega = [0.0, float(m), 0.0, float(n)]
-    levels = num_levels(m, n)
+    levels = 1 if single_level else num_levels(m, n)
+    if np.isscalar(optPara["outerIter"]):
+        optPara = dict(optPara, outerIter=[optPara["outerIter"]] * 2)
+    if np.isscalar(optPara["nu_factor"]):
+        optPara = dict(optPara, nu_factor=[optPara["nu_factor"]] * 2)
     max_outer = int(max(optPara["outerIter"]))
     u = [[None] * max_outer for _ in range(levels)]
     L = [[None] * max_outer for _ in range(levels)]
@@ -242,17 +246,20 @@ def mf_nn_curvature_registration_no_ref_ml(img, optPara, **kw):
 
 
 # ------------------------------------------------------------------------------------------------
-def _var_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True):
+def _var_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True, single_level=False):
     """NNE/var_tv_registration_no_ref_ml.m:40-197 (and var_curvature...): multi-level loop, outer linearisations,
     power iteration, CP solve; everything but the loop control stays on the device."""
     k = len(img)
     img = [normalize(im) for im in img]
     m, n = img[0].shape
     omega = [0.0, float(m), 0.0, float(n)]
-    levels = num_levels(m, n)                                                           # (:58)
+    levels = 1 if single_level else num_levels(m, n)                                    # (:58)
+    if np.isscalar(optPara["outerIter"]):
+        optPara = dict(optPara, outerIter=[optPara["outerIter"]] * 2)
     max_outer = int(max(optPara["outerIter"]))
     u = [[None] * max_outer for _ in range(levels)]
     model = E.MODEL_VAR_TV if reg == "tv" else E.MODEL_VAR_CURV
+    flags = E.FLAG_VAR_SSD_SWAP if single_level else 0        # NNE/var_tv_registration_no_ref.m:173
     sizes = [(m, n)]
     for _ in range(levels - 1):
         sizes.insert(0, ((sizes[0][0] + 1) // 2, (sizes[0][1] + 1) // 2))
@@ -261,7 +268,7 @@ def _var_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_al
         for (ml, nl) in sizes:
             h_grid = ((omega[1] - omega[0]) / ml, (omega[3] - omega[2]) / nl)          # (:85)
             engines.append(E.Engine(model, ml, nl, k=k, bc=optPara["bc"], h=h_grid, omega=omega, mu=optPara["mu"],
-                                    device=device))
+                                    device=device, flags=flags))
         engines[-1].set_images(np.concatenate([_vecF(im) for im in img]))
         for lev in range(levels - 1, 0, -1):
             engines[lev].downsample_to(engines[lev - 1])                                # (:71-74)
@@ -302,3 +309,16 @@ def var_curvature_registration_no_ref_ml(img, optPara, **kw):
     """u = var_curvature_registration_no_ref_ml(img, optPara)   (NNE/var_curvature_registration_no_ref_ml.m:7);
     the Laplacian's boundary condition comes from optPara['bc'] (the reference omits the argument, :119)."""
     return _var_ml(img, optPara, "curvature", **kw)
+
+
+def mf_nn_tv_registration_no_ref(img, optPara, **kw):
+    """[u, L, SV_history] = mf_nn_tv_registration_no_ref(img, optPara)   (NNE/mf_nn_tv_registration_no_ref.m): the
+    single-level predecessor of the _ml driver (scalar outerIter / nu_factor, h = 1); u, L are lists over outer iterations"""
+    u, L, SV = _mf_nn_ml(img, optPara, "tv", single_level=True, **kw)
+    return u[0], L[0], SV[0]
+
+
+def var_tv_registration_no_ref(img, optPara, **kw):
+    """u = var_tv_registration_no_ref(img, optPara)   (NNE/var_tv_registration_no_ref.m), incl. its swapped SSD prox
+    arguments (:173)"""
+    return _var_ml(img, optPara, "tv", single_level=True, **kw)[0]

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("CP_ENGINE_LIB", os.path.join(_HERE, "libcpengine.so")
 
 MODEL_TV_L1_DENOISE, MODEL_TV_L1_REG, MODEL_TV_L2_REG, MODEL_MF_NN_TV, MODEL_MF_NN_CURV = 1, 2, 3, 4, 5
 MODEL_VAR_TV, MODEL_VAR_CURV = 6, 7
+FLAG_VAR_SSD_SWAP = 1
 BC = {"neumann": 0, "linear": 1, "dirichlet": 2}
 STOP_MAXITER, STOP_TOLERANCE = 0, 1
 
@@ -20,7 +21,7 @@ STOP_MAXITER, STOP_TOLERANCE = 0, 1
 class ProblemDesc(C.Structure):
     _fields_ = [
         ("model", C.c_int32), ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
-        ("bc", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("reserved0", C.c_int32),
+        ("bc", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32), ("flags", C.c_int32),
         ("h", C.c_double * 2), ("omega", C.c_double * 4),
         ("lambda_", C.c_double), ("mu", C.c_double),
         ("n_global", C.c_int32), ("j_offset", C.c_int32),
@@ -123,7 +124,7 @@ class Engine:
     """One handle = one (F, G, K) triple of the reference at one resolution."""
 
     def __init__(self, model, m, n, k=1, bc="neumann", h=(1.0, 1.0), omega=None, lam=0.0, mu=0.0, device=0,
-                 batch=1, n_global=0, j_offset=0):
+                 batch=1, n_global=0, j_offset=0, flags=0):
         d = ProblemDesc()
         d.model, d.m, d.n, d.k = model, m, n, k
         if bc not in BC:
@@ -135,6 +136,7 @@ class Engine:
                 d.omega[i] = float(omega[i])
         d.lambda_, d.mu = float(lam), float(mu)
         d.n_global, d.j_offset = n_global, j_offset
+        d.flags = flags
         self.desc = d
         self.model, self.m, self.n, self.k, self.batch = model, m, n, k, batch
         self.var = model in (MODEL_VAR_TV, MODEL_VAR_CURV)

@@ -110,7 +110,7 @@ def mf_nn_G(x, s, conjugate_flag, nargout):
     return a1 + a2, max(c1, c2), None
 
 
-def mf_nn_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start, keep=None):
+def mf_nn_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start, keep=None, single_level=False):
     """[u, L, SV_history] = mf_nn_{tv,curvature}_registration_no_ref_ml(img, optPara).
 
     `keep` (dict) receives diagnostics per (lev, o): nu, tau, norm estimate, histories.
@@ -120,7 +120,12 @@ def mf_nn_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_star
     img = [normalize(im) for im in img]                                          # (:49-51)
     m, n = img[0].shape
     omega = [0.0, float(m), 0.0, float(n)]
-    numLevels = ops.num_levels(m, n)                                             # (:59)
+    # single_level: NNE/mf_nn_tv_registration_no_ref.m (one level, scalar outerIter / nu_factor, h = 1)
+    numLevels = 1 if single_level else ops.num_levels(m, n)                      # (:59)
+    if np.isscalar(optPara["outerIter"]):
+        optPara = dict(optPara, outerIter=[optPara["outerIter"]] * 2)
+    if np.isscalar(optPara["nu_factor"]):
+        optPara = dict(optPara, nu_factor=[optPara["nu_factor"]] * 2)
     max_outer = int(max(optPara["outerIter"]))
     u = [[None] * max_outer for _ in range(numLevels)]
     L = [[None] * max_outer for _ in range(numLevels)]
@@ -225,7 +230,7 @@ def mf_nn_problem(ML_lev, u0, h_grid, omega, reg, bc):
 
 # --------------------------------------------------------------------------
 # NNE/var_tv_registration_no_ref_ml.m / NNE/var_curvature_registration_no_ref_ml.m
-def var_F(y, b, k, h_grid, mu, sigma, conjugate_flag, nargout, reg):
+def var_F(y, b, k, h_grid, mu, sigma, conjugate_flag, nargout, reg, ssd_swap=False):
     """Local function F of the variance drivers (var_tv...:201-260; var_curvature...:199-252); `b` is the second
     SSD argument as passed by the caller (the drivers pass -B*b, var_tv...:172)."""
     ncomp = 5 if reg == "tv" else 3
@@ -235,7 +240,10 @@ def var_F(y, b, k, h_grid, mu, sigma, conjugate_flag, nargout, reg):
     hh = float(np.prod(h_grid))
     if nargout == 3:
         res3 = np.zeros(ncomp * k * mn)
-        res3[: k * mn] = px.SSD(y1, b, hh, sigma, conjugate_flag, 3)[2]
+        if ssd_swap:    # NNE/var_tv_registration_no_ref.m:173 (single-level driver): lambda and tau exchanged
+            res3[: k * mn] = px.SSD(y1, b, sigma, hh, conjugate_flag, 3)[2]
+        else:
+            res3[: k * mn] = px.SSD(y1, b, hh, sigma, conjugate_flag, 3)[2]
         if reg == "tv":
             Y2 = y2.reshape((4 * mn, k), order="F")
             for j in range(k):
@@ -280,7 +288,7 @@ def var_problem(ML_lev, u0, h_grid, omega, reg, bc):
     return sp.vstack([A1, A2], format="csr"), b, T_u, gs
 
 
-def var_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start, keep=None):
+def var_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start, keep=None, single_level=False):
     """u = var_{tv,curvature}_registration_no_ref_ml(img, optPara)  (var_tv...:7-197).
 
     Quirks kept: the prolongation multiplies by 2 (:112). NNE/var_curvature...:119 calls discrete_laplacian without
@@ -289,8 +297,11 @@ def var_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start,
     img = [normalize(im) for im in img]
     m, n = img[0].shape
     omega = [0.0, float(m), 0.0, float(n)]
-    numLevels = ops.num_levels(m, n)
-    max_outer = int(max(optPara["outerIter"]))
+    # single_level: NNE/var_tv_registration_no_ref.m (one level, scalar outerIter, h = 1, swapped SSD prox arguments :173)
+    numLevels = 1 if single_level else ops.num_levels(m, n)
+    oi = optPara["outerIter"]
+    oi = [int(oi), int(oi)] if np.isscalar(oi) else [int(v) for v in oi]
+    max_outer = max(oi)
     u = [[None] * max_outer for _ in range(numLevels)]
     ML = [ops.pyramid(im, numLevels) for im in img]
     ncomp = 5 if reg == "tv" else 3
@@ -299,7 +310,7 @@ def var_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start,
         m, n = ML[0][lev].shape
         h_grid = np.array([(omega[1] - omega[0]) / m, (omega[3] - omega[2]) / n])
         theta, tol, mu, bc, maxIter = optPara["theta"], optPara["tol"], optPara["mu"], optPara["bc"], optPara["maxIter"]
-        outerIter = int(optPara["outerIter"][0 if lev == 0 else 1])
+        outerIter = oi[0 if lev == 0 else 1]
         if lev == 0:
             x = np.zeros(2 * k * m * n)
         else:
@@ -315,7 +326,7 @@ def var_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start,
             norm_A_est = e[-1]
             tau = np.sqrt(0.99 / norm_A_est ** 2)                                # (:168-169)
             sigma = np.sqrt(0.99 / norm_A_est ** 2)
-            Fh = lambda y, c, nargout, b_=b, sg=sigma: var_F(y, -b_, k, h_grid, mu, sg, c, nargout, reg)   # (:172)
+            Fh = lambda y, c, nargout, b_=b, sg=sigma: var_F(y, -b_, k, h_grid, mu, sg, c, nargout, reg, ssd_swap=single_level)   # (:172)
             x, p, ph, dh = chambolle_pock(Fh, Gh, A, x, p, theta, tau, sigma, maxIter, tol)
             u0 = x.reshape((m * n, 2, k), order="F")
             u[lev][o] = u0.copy()

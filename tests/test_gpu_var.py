@@ -106,3 +106,29 @@ def test_var_iterate_in_parts():
             eng.singular_values(1)
         eng.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_single_level_drivers():
+    """NNE/var_tv_registration_no_ref.m (swapped SSD prox arguments, :173) and NNE/mf_nn_tv_registration_no_ref.m"""
+    from ma_amd import drivers as D, synth
+    from oracle import drivers as od
+    m, n, k = 72, 80, 3           # the _ml drivers would use 2 levels here
+    imgs = [synth.dynamic_test_image(m, n, k).numpy()[i] for i in range(k)]
+    opt = dict(theta=1.0, maxIter=40, tol=1e-3, outerIter=2, mu=0.1, bc="neumann")
+    keep_r, keep_g = {}, {}
+    ur = od.var_registration_no_ref_ml(imgs, opt, "tv", keep=keep_r, single_level=True)[0]
+    ug = D.var_tv_registration_no_ref(imgs, opt, keep=keep_g)
+    assert set(keep_g) == {(0, 0), (0, 1)} == set(keep_r)
+    for key in keep_r:
+        np.testing.assert_allclose(keep_g[key]["dual_history"], keep_r[key]["dual_history"], rtol=1e-8, atol=1e-9)
+    for o in range(2):
+        assert _rel(ug[o], ur[o]) < 1e-9
+    # the swap matters: the _ml arithmetic gives a different iterate
+    u_ml = od.var_registration_no_ref_ml(imgs, dict(opt, outerIter=[2, 2]), "tv", single_level=False)
+    assert len(u_ml) == 2
+    opt2 = dict(theta=1.0, maxIter=30, tol=1e-3, outerIter=2, mu=0.2, nu_factor=0.9, bc="neumann")
+    ur2, Lr2, SVr2 = od.mf_nn_registration_no_ref_ml(imgs, opt2, "tv", single_level=True)
+    ug2, Lg2, SVg2 = D.mf_nn_tv_registration_no_ref(imgs, opt2)
+    for o in range(2):
+        assert _rel(ug2[o], ur2[0][o]) < 1e-9 and _rel(Lg2[o], Lr2[0][o]) < 1e-9
+    np.testing.assert_allclose(SVg2, SVr2[0], rtol=1e-9, atol=1e-10)
