@@ -103,3 +103,45 @@ def test_iterate_in_parts_is_bitwise_iterate(reg, k):
         out.append((eng.primal(), eng.dual()))
         eng.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("reg,bc,m,n,k", [("tv", "neumann", 5, 3, 2), ("tv", "linear", 3, 6, 2), ("tv", "neumann", 2, 2, 16),
+                                          ("tv", "neumann", 130, 3, 16), ("tv", "neumann", 7, 9, 1),
+                                          ("curvature", "neumann", 3, 4, 2), ("curvature", "dirichlet", 2, 67, 1)])
+def test_extreme_shapes(reg, bc, m, n, k):
+    """smallest grids (2 pixels per axis), single image (B*L = 0), strips narrower than a wave, K at its maximum"""
+    from ma_amd import engine as E
+    from oracle import drivers as od
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    rng = np.random.default_rng(m * 100 + n * 10 + k)
+    imgs = rng.random((k, m, n))
+    u0 = 0.3 * rng.standard_normal((k, 2, n * m))
+    u0_ref = np.transpose(u0, (2, 1, 0))
+    omega = [0.0, float(m), 0.0, float(n)]
+    h = (1.0, 1.0)
+    A, b, T_u, gs = od.mf_nn_problem([imgs[i] for i in range(k)], u0_ref, h, omega, reg, bc)
+    mu = 0.2 if reg == "tv" else 2.0
+    nu, tau, sigma = 0.5 * k, 0.2, 0.2
+    kmn = k * m * n
+    ncomp = 6 if reg == "tv" else 4
+    x0 = np.concatenate([u0.reshape(-1), 0.5 * T_u.reshape(-1, order="F")])
+    y0 = 0.01 * rng.standard_normal(ncomp * kmn)
+    Fh = lambda y, c, nargout: od.mf_nn_F(y, b, k, h, mu, nu, sigma, c, nargout, reg)
+    Gh = lambda x, c, nargout: od.mf_nn_G(x, (m, n, k), c, nargout)
+    xr, yr, phr, dhr = cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, sigma, 12, 1e-3)
+    eng = E.Engine(E.MODEL_MF_NN_TV if reg == "tv" else E.MODEL_MF_NN_CURV, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu)
+    eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+    eng.set_primal(x0)
+    eng.linearize()
+    eng.set_dual(y0)
+    eng.set_nu(nu)
+    eng.solve(1.0, tau, sigma, 12, 1e-3)
+    x, y = eng.primal(), eng.dual()
+    ph, dh = eng.history()
+    eng.close()
+    assert ph.shape == phr.shape
+    np.testing.assert_allclose(ph[:, :5], phr[:, :5], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(dh[:, :5], dhr[:, :5], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(ph[:, 5:], phr[:, 5:], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(dh[:, 5:], dhr[:, 5:], rtol=0, atol=1e-8)
+    assert _rel(x, xr) < TOL and _rel(y, yr) < TOL
