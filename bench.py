@@ -116,7 +116,7 @@ def main():
     backend = os.environ.get("CP_BENCH_BACKEND", "nccl")
     if backend == "gloo":
         local_rank = 0
-    if world > 1:
+    if world > 1 or os.environ.get("CP_FORCE_SLAB_PATH", "0") == "1":
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -238,7 +238,7 @@ def main():
                           f"{args.cpu_size}^2 x K={k} in {cdt:.1f} s, scaled by pixel count to {m}^2"}
         print(json.dumps(out), flush=True)
     solver.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

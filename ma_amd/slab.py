@@ -3,6 +3,8 @@
 The device layout is [field][j][i] with i (image rows) contiguous; the image is split along j into
 `world` contiguous slabs.  world == 1 is the plain single-GPU engine.
 """
+import os
+
 import numpy as np
 
 from . import engine as E
@@ -25,7 +27,9 @@ class SlabSolver:
     def __init__(self, model, m, n, k, bc, h, omega, mu, device, part):
         self.part = part
         self.m, self.n, self.k = m, n, k
-        if part.world == 1:
+        # CP_FORCE_SLAB_PATH=1 (tests): run the multi-GPU driver on a single rank too, so that the RCCL code path
+        # (device-tensor all-gather, stream hand-over) is exercised on a one-GPU box
+        if part.world == 1 and os.environ.get("CP_FORCE_SLAB_PATH", "0") != "1":
             self.eng = E.Engine(model, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu, device=device)
         else:
             from .slab_mg import MultiGpuEngine

@@ -18,3 +18,14 @@ def test_slabs_match_single_gpu(world, k):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0
+
+
+def test_rccl_backend_single_rank():
+    """the multi-GPU driver over the RCCL backend (device-tensor all-gather, torch stream hand-over) on one rank"""
+    env = dict(os.environ, CP_FORCE_SLAB_PATH="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29431", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--size", "512", "--k", "16",
+           "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=250)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0 and '"metric"' in r.stdout
