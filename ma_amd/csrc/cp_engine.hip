@@ -900,7 +900,7 @@ static int pw_iterations(cp_engine *h, const PwParams &P, int n0, int count, int
         launch_pw_primal<0>(h, P, h->X[cur], h->X[nxt], h->P[nxt]);
         CPCHK(timer_end(h, T_PRIMAL));
         CPCHK(timer_begin(h, T_FIN));
-        hipLaunchKernelGGL(k_pw_fin, dim3(h->batch), dim3(64), 0, h->stream, pw_fin_args(h, n - 1, n, n, check, tol),
+        hipLaunchKernelGGL(k_pw_fin, dim3(h->batch), dim3(PW_FIN_THREADS), 0, h->stream, pw_fin_args(h, n - 1, n, n, check, tol),
                            h->part, h->part2, ctrl, h->hist_p, h->hist_d);
         CPCHK(timer_end(h, T_FIN));
     }
@@ -921,7 +921,7 @@ static int solve_pw(cp_engine *h, double theta, double tau, double sigma, int ma
     // row 0
     launch_pw_dual<1>(h, P, h->X[0], h->X[1], h->P[0], nullptr);
     launch_pw_primal<1>(h, P, h->X[0], nullptr, h->P[0]);
-    hipLaunchKernelGGL(k_pw_fin, dim3(h->batch), dim3(64), 0, h->stream, pw_fin_args(h, 0, 0, 0, 0, tol), h->part,
+    hipLaunchKernelGGL(k_pw_fin, dim3(h->batch), dim3(PW_FIN_THREADS), 0, h->stream, pw_fin_args(h, 0, 0, 0, 0, tol), h->part,
                        h->part2, ctrl, h->hist_p, h->hist_d);
     HIPCHK(hipGetLastError());
     std::vector<PwCtrl> hc(h->batch);
@@ -941,7 +941,7 @@ static int solve_pw(cp_engine *h, double theta, double tau, double sigma, int ma
     {
         const int cur = maxIter & 1;
         launch_pw_dual<1>(h, P, h->X[cur], h->X[cur ^ 1], h->P[cur], nullptr);
-        hipLaunchKernelGGL(k_pw_fin, dim3(h->batch), dim3(64), 0, h->stream, pw_fin_args(h, maxIter, -1, -1, 0, tol),
+        hipLaunchKernelGGL(k_pw_fin, dim3(h->batch), dim3(PW_FIN_THREADS), 0, h->stream, pw_fin_args(h, maxIter, -1, -1, 0, tol),
                            h->part, h->part2, ctrl, h->hist_p, h->hist_d);
         HIPCHK(hipGetLastError());
     }

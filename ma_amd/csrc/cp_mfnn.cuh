@@ -163,16 +163,19 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
                     // neighbours (offset-invariant differences are still taken on true values)
                     double uxi, uyi, uxj, uyj, uxbi, uybi, uxbj, uybj;   // "next" along i / j (or previous at a linear boundary)
                     {
+                        // neighbour loads are unconditional (halo columns make them legal), selection afterwards
                         const int oi = last_i ? -1 : 1;
                         const bool need_i = !last_i || linear;
-                        const double a0 = need_i ? uxc[oi] - ccx : 0.0, a1 = need_i ? uyc[oi] - ccy : 0.0;
-                        const double o0 = need_i ? uxo[oi] - cox : 0.0, o1 = need_i ? uyo[oi] - coy : 0.0;
-                        uxi = a0; uyi = a1;
-                        uxbi = a0 + theta * (a0 - o0); uybi = a1 + theta * (a1 - o1);
+                        const double ra0 = uxc[oi], ra1 = uyc[oi], ro0 = uxo[oi], ro1 = uyo[oi];
                         const int oj = last_j ? -m : m;
                         const bool need_j = !last_j || linear;
-                        const double c0 = need_j ? uxc[oj] - ccx : 0.0, c1 = need_j ? uyc[oj] - ccy : 0.0;
-                        const double p0 = need_j ? uxo[oj] - cox : 0.0, p1 = need_j ? uyo[oj] - coy : 0.0;
+                        const double rc0 = uxc[oj], rc1 = uyc[oj], rp0 = uxo[oj], rp1 = uyo[oj];
+                        const double a0 = need_i ? ra0 - ccx : 0.0, a1 = need_i ? ra1 - ccy : 0.0;
+                        const double o0 = need_i ? ro0 - cox : 0.0, o1 = need_i ? ro1 - coy : 0.0;
+                        uxi = a0; uyi = a1;
+                        uxbi = a0 + theta * (a0 - o0); uybi = a1 + theta * (a1 - o1);
+                        const double c0 = need_j ? rc0 - ccx : 0.0, c1 = need_j ? rc1 - ccy : 0.0;
+                        const double p0 = need_j ? rp0 - cox : 0.0, p1 = need_j ? rp1 - coy : 0.0;
                         uxj = c0; uyj = c1;
                         uxbj = c0 + theta * (c0 - p0); uybj = c1 + theta * (c1 - p1);
                     }
@@ -220,13 +223,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
                         const bool have[4] = {!first_i, !last_i, !first_j, !last_j};
                         const int off[4] = {-1, 1, -m, m};
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            if (have[d]) {
-                                const double a = pc[off[d]] - oc, o = po[off[d]] - oo;
-                                nb[d] = a; nbb[d] = a + theta * (a - o);
-                            } else {
-                                nb[d] = neumann ? uc0 : 0.0; nbb[d] = neumann ? ub0 : 0.0;
-                            }
+                        for (int d = 0; d < 4; ++d) {   // unconditional loads (halo), selection afterwards
+                            const double ra = pc[off[d]], ro = po[off[d]];
+                            const double a = ra - oc, o = ro - oo;
+                            nb[d] = have[d] ? a : (neumann ? uc0 : 0.0);
+                            nbb[d] = have[d] ? a + theta * (a - o) : (neumann ? ub0 : 0.0);
                         }
                         lapc[c] = (nb[0] + nb[1] - 2.0 * uc0) * ih1 + (nb[2] + nb[3] - 2.0 * uc0) * ih2;
                         lapb[c] = (nbb[0] + nbb[1] - 2.0 * ub0) * ih1 + (nbb[2] + nbb[3] - 2.0 * ub0) * ih2;

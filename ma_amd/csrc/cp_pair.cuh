@@ -198,28 +198,41 @@ struct PwFinArgs {
     double tol, lambda;
 };
 
-// one workgroup per problem
-__global__ __launch_bounds__(64) void k_pw_fin(PwFinArgs A, const double *__restrict__ partD,
-                                               const double *__restrict__ partP, PwCtrl *ctrl, double *hist_p_,
-                                               double *hist_d_) {
+// one workgroup (256 threads) per problem: 32 sub-groups stride the per-block partials of the 8 slots (4 dual, 4
+// primal), then a fixed-order combine -- deterministic, and identical for a problem alone or inside a batch
+#define PW_FIN_THREADS 256
+__global__ __launch_bounds__(PW_FIN_THREADS) void k_pw_fin(PwFinArgs A, const double *__restrict__ partD,
+                                                           const double *__restrict__ partP, PwCtrl *ctrl,
+                                                           double *hist_p_, double *hist_d_) {
+    __shared__ double stage[PW_FIN_THREADS], tot[8];
     const int prob = blockIdx.x;
     if (ctrl[prob].stop) return;
-    const int lane = threadIdx.x;
+    const int t = threadIdx.x, slot8 = t & 7, sub = t >> 3;
     const double *pd = partD + (size_t)prob * A.nblk * PW_PSTRIDE, *pp = partP + (size_t)prob * A.nblk * PW_PSTRIDE;
-    // lanes 0..3: slots of the dual partials, 4..7: slots of the primal partials (fixed block order)
-    double v = 0.0;
-    if (lane < 8) {
-        const double *src = (lane < 4) ? pd : pp;
-        const int slot = lane & 3;
-        v = src[slot];
-        for (int bI = 1; bI < A.nblk; ++bI) {
+    {
+        const double *src = (slot8 < 4) ? pd : pp;
+        const int slot = slot8 & 3;
+        const bool is_sum = slot < PW_NS;
+        double v = 0.0;                                   // all maxima are of non-negative quantities
+        for (int bI = sub; bI < A.nblk; bI += PW_FIN_THREADS / 8) {
             const double o = src[(size_t)bI * PW_PSTRIDE + slot];
-            v = (slot < PW_NS) ? v + o : fmax(v, o);
+            v = is_sum ? v + o : fmax(v, o);
         }
+        stage[t] = v;
     }
-    const double tvsum = __shfl(v, 0, 64), vmax = __shfl(v, 2, 64);
-    const double gsum = __shfl(v, 4, 64), gssum = __shfl(v, 5, 64), gscon = __shfl(v, 6, 64);
-    if (lane != 0) return;
+    __syncthreads();
+    if (t < 8) {
+        const bool is_sum = (t & 3) < PW_NS;
+        double v = stage[t];
+        for (int u = 1; u < PW_FIN_THREADS / 8; ++u) {
+            const double o = stage[u * 8 + t];
+            v = is_sum ? v + o : fmax(v, o);
+        }
+        tot[t] = v;
+    }
+    __syncthreads();
+    if (t != 0) return;
+    const double tvsum = tot[0], vmax = tot[2], gsum = tot[4], gssum = tot[5], gscon = tot[6];
     double *hist_p = hist_p_ + (size_t)prob * A.hist_rows * CP_HCOLS_PW;
     double *hist_d = hist_d_ + (size_t)prob * A.hist_rows * CP_HCOLS_PW;
     if (A.rpG >= 0) {

@@ -1,0 +1,45 @@
+"""Secondary workloads of SURVEY.md section 8(d): C2 (TV-L1 2048^2), C5 (256 x 512^2 TV-L2 batch), C4-curvature,
+var-TV; prints iterations/s and algorithmic GB/s (elements per pixel from section 8d)."""
+import sys, os, time, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ma_amd import engine as E, synth
+
+def run(name, eng, theta, tau, sigma, iters, bytes_iter):
+    eng.iterate_begin(theta, tau, sigma, 2 * iters + 4)
+    eng.iterate_steps(4); eng.sync()
+    for p in ("dual", "primal", "eig", "fin"): eng.kernel_time_ms(p)
+    t0 = time.perf_counter(); eng.iterate_steps(iters); eng.sync(); dt = time.perf_counter() - t0
+    times = {p: eng.kernel_time_ms(p) for p in ("dual", "primal", "eig", "fin")}
+    eng.iterate_end(); eng.sync()
+    print(json.dumps({"workload": name, "it_per_s": iters / dt, "ms_per_it": dt / iters * 1e3,
+                      "algorithmic_GBps": bytes_iter * iters / dt / 1e9,
+                      "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in times.items()}}), flush=True)
+
+which = sys.argv[1:] or ["c2", "c5", "c4", "var"]
+if "c2" in which:
+    m = n = 2048
+    fr = synth.dynamic_test_image(m, n, 2).numpy()
+    eng = E.Engine(E.MODEL_TV_L1_REG, m, n, lam=0.7)
+    eng.set_images(fr[1].reshape(-1, order="F"), fr[0].reshape(-1, order="F")); eng.set_primal(np.zeros(2*m*n)); eng.linearize()
+    tau = 5.0; run("C2 TV-L1 2048^2", eng, 1.0, tau, (1 - 1e-4) / (8 * tau), 100, 23 * 8.0 * m * n); eng.close()
+if "c5" in which:
+    m = n = 512; B = 256
+    fr = synth.dynamic_test_image(m, n, 2).numpy()
+    T = np.tile(fr[1].reshape(-1, order="F"), B); R = np.tile(fr[0].reshape(-1, order="F"), B)
+    eng = E.Engine(E.MODEL_TV_L2_REG, m, n, lam=50.0, batch=B)
+    eng.set_images(T, R); eng.set_primal(np.zeros(2*m*n*B)); eng.linearize()
+    tau = 4.0; run("C5 TV-L2 256 x 512^2", eng, 1.0, tau, (1 - 1e-4) / (8 * tau), 100, 23 * 8.0 * m * n * B); eng.close()
+for tag, model, el, mu in (("c4", E.MODEL_MF_NN_CURV, 31, 20.0), ("var", E.MODEL_VAR_TV, 28, 0.1)):
+    if tag not in which: continue
+    m = n = 4096; k = 16
+    dev = torch.device("cuda", 0)
+    imgs = synth.dynamic_test_image(m, n, k, device=dev).transpose(1, 2).contiguous().cpu().numpy().reshape(-1)
+    u0 = synth.smooth_displacement(m, n, k, amp=2.0, device=dev).cpu().numpy().reshape(-1)
+    torch.cuda.empty_cache()
+    eng = E.Engine(model, m, n, k=k, bc="dirichlet" if tag == "c4" else "neumann", omega=[0.0, float(m), 0.0, float(n)], mu=mu)
+    eng.set_images(imgs)
+    eng.set_primal(np.concatenate([u0, np.zeros(k*m*n)]) if tag == "c4" else u0); eng.linearize()
+    if tag == "c4": eng.set_nu(30.0)
+    run(("C4 NN-curvature" if tag == "c4" else "var-TV") + " 4096^2 x 16", eng, 1.0, 0.1, 0.1, 20, el * 8.0 * k * m * n); eng.close()
