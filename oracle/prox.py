@@ -379,3 +379,27 @@ def SSD_registration(u, u0, T, R, h, lam, tau, conjugate_flag=False, nargout=2):
         # reference branch (:113-116) has a shape bug (u is mn x 2 there) and is never reached
         raise NotImplementedError("prox of SSD_registration conjugate is unreachable in the reference")
     return res1, res2, None
+
+
+# --------------------------------------------------------------------------
+# NNE/nuclear_norm.m:1-84   mu * || L ||_*  (soft constraint used by the archived drivers / test_nuclear_norm_measure.m)
+def nuclear_norm(L, numImg, tau, mu, conjugate_flag=False, nargout=2):
+    Lm = np.asarray(L, dtype=np.float64).reshape((-1, numImg), order="F")
+    res2 = 0.0
+    if not conjugate_flag:
+        U, S, Vt = np.linalg.svd(Lm, full_matrices=False)
+        res1 = mu * np.sum(np.abs(S))
+        if nargout == 3:
+            St = np.maximum(S - mu * tau, 0)
+            return res1, res2, ((U * St) @ Vt).reshape(-1, order="F")
+        return res1, res2, None
+    Lm = Lm / mu
+    S = np.linalg.svd(Lm, compute_uv=False)
+    res1 = mu * 0.0
+    if np.max(S) > 1:
+        res2 = np.max(S) - 1
+    if nargout == 3:
+        Lv = Lm.reshape(-1, order="F")
+        _, _, prox = nuclear_norm(Lv / (mu * tau), numImg, 1.0 / tau, 1.0 / mu, False, 3)
+        return res1, res2, Lv - mu * tau * prox
+    return res1, res2, None

@@ -164,3 +164,20 @@ def test_pyramid_and_prolongation():
     X = x.reshape((3, 4), order="F")
     assert P[4, 6] == X[2, 3] and P[1, 1] == X[0, 0] and P[2, 1] == X[1, 0]
     assert oo.num_levels(64, 48) == 1 and oo.num_levels(200, 200) == 3 and oo.num_levels(4096, 4096) == 8
+
+
+def test_soft_nuclear_norm_moreau():
+    """NNE/nuclear_norm.m: prox and conjugate prox satisfy x = prox_{tau f}(x) + tau prox_{f*/tau}(x/tau) in the scaled
+    form the file uses; singular values are soft-thresholded"""
+    from oracle import prox as px
+    rng = np.random.default_rng(2)
+    k, mn = 4, 30
+    L = rng.standard_normal(mn * k)
+    tau, mu = 0.7, 0.9
+    val, con, p = px.nuclear_norm(L, k, tau, mu, False, 3)
+    S = np.linalg.svd(L.reshape((mn, k), order="F"), compute_uv=False)
+    Sp = np.linalg.svd(p.reshape((mn, k), order="F"), compute_uv=False)
+    assert np.isclose(val, mu * S.sum()) and con == 0.0
+    assert np.allclose(Sp, np.maximum(S - mu * tau, 0), atol=1e-12)
+    _, con_c, _ = px.nuclear_norm(L, k, tau, mu, True, 2)
+    assert np.isclose(con_c, max(S.max() / mu - 1, 0))
