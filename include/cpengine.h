@@ -181,13 +181,17 @@ int cp_kernel_time_ms(cp_handle h, const char *pass, double *ms, int64_t *launch
  * pointers passed in are caller-owned device memory; kernels run on the stream given to cp_set_stream
  * (e.g. torch's current stream), so the caller's collectives on that stream are ordered with them.   */
 enum { CP_BUF_X0 = 0, CP_BUF_X1 = 1, CP_BUF_P0 = 2, CP_BUF_P1 = 3, CP_BUF_XTMP = 4 };
-enum { CP_SEL_ALL = 0, CP_SEL_X_U = 1, CP_SEL_P_Y12 = 2, CP_SEL_P_DY = 3 };
+enum { CP_SEL_ALL = 0, CP_SEL_X_U = 1, CP_SEL_P_Y12 = 2, CP_SEL_P_DY = 3,
+       CP_SEL_P_Y2 = 4      /* all y2 fields (4K TV, 2K curvature): split passes, both directions */ };
 enum { CP_STAGE_DUAL0 = 0,   /* dual step 1 alone (first kernel of a solve) + local reduction -> red      */
        CP_STAGE_EIG0 = 1,    /* eigensolve on the gathered partials of DUAL0                               */
        CP_STAGE_FUSED = 2,   /* k_mf_fused_tv for iteration n + local reduction -> red                     */
        CP_STAGE_EFUSED = 3,  /* k_mf_efused for iteration n on the gathered partials                       */
        CP_STAGE_APPLY_A = 4, /* power iteration: P1 = A * (scale * X1)                                     */
-       CP_STAGE_APPLY_AT = 5 /* power iteration: XTMP = A' * P1, local sum of squares -> red[0]; swaps X1/XTMP */ };
+       CP_STAGE_APPLY_AT = 5, /* power iteration: XTMP = A' * P1, local sum of squares -> red[0]; swaps X1/XTMP */
+       /* split passes (NN-curvature; also NN-TV): iteration n = DUAL -> gather -> EIG -> halo(y2) -> PRIMAL -> gather
+        * -> FIN -> halo(u)                                                                                    */
+       CP_STAGE_SPLIT_DUAL = 6, CP_STAGE_SPLIT_EIG = 7, CP_STAGE_SPLIT_PRIMAL = 8, CP_STAGE_SPLIT_FIN = 9 };
 int cp_set_stream(cp_handle h, void *hip_stream);          /* NULL = the handle's own stream            */
 int64_t cp_mg_partial_len(void);                           /* doubles per reduced partial vector        */
 int64_t cp_mg_halo_len(cp_handle h, int sel);              /* doubles per packed halo column            */

@@ -211,8 +211,9 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (d.bc < 0 || d.bc > 2) CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");
         if (d.batch > 1) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported batch > 1 for mf_nn models");
         if (d.n_global > 0 && d.n_global != d.n) {
-            if (d.model != CP_MODEL_MF_NN_TV || d.bc != CP_BC_NEUMANN)
-                CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported row slabs need the NN-TV model with neumann boundary");
+            // the linear boundary row couples every column with the last one (finite_difference_operator.m:31)
+            if (var || d.bc == CP_BC_LINEAR)
+                CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported row slabs need an mf_nn model with neumann or dirichlet boundary");
             if (d.j_offset < 0 || d.j_offset + d.n > d.n_global)
                 CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg slab [%d, %d) outside [0, %d)", d.j_offset, d.j_offset + d.n, d.n_global);
         }
@@ -1207,6 +1208,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_halo_copy(int m, int fs, int nsel,
         const int s = gid / m, i = gid - s * m;
         int f = s;                                                  // CP_SEL_ALL, CP_SEL_X_U, CP_SEL_P_Y12: leading fields
         if (sel == CP_SEL_P_DY) f = K + 4 * (s >> 1) + 1 + 2 * (s & 1);   // Dy u_x, Dy u_y of image s/2
+        if (sel == CP_SEL_P_Y2) f = K + s;                                 // all y2 fields
         double *p = buf + (size_t)f * fs + (size_t)col * m + i;
         if (pack) lin[gid] = *p; else *p = lin[gid];
     }
@@ -1230,8 +1232,9 @@ static int mg_nsel(const cp_engine *h, int buf, int sel) {
     switch (sel) {
         case CP_SEL_ALL: return isx ? h->nxf : h->npf;
         case CP_SEL_X_U: return isx ? 2 * h->K : -1;
-        case CP_SEL_P_Y12: return isx ? -1 : 5 * h->K;
-        case CP_SEL_P_DY: return isx ? -1 : 2 * h->K;
+        case CP_SEL_P_Y12: return (isx || h->reg != 0) ? -1 : 5 * h->K;
+        case CP_SEL_P_DY: return (isx || h->reg != 0) ? -1 : 2 * h->K;
+        case CP_SEL_P_Y2: return isx ? -1 : (h->reg == 0 ? 4 : 2) * h->K;
     }
     return -1;
 }
@@ -1278,7 +1281,7 @@ extern "C" int cp_mg_halo_unpack(cp_handle h, int buf, int sel, int side, const 
 }
 
 extern "C" int cp_mg_begin(cp_handle h, double theta, double tau, double sigma) {
-    if (!h || !h->mf || h->var || h->reg != 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_begin needs an NN-TV handle");
+    if (!h || !h->mf || h->var) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_begin needs an mf_nn handle");
     HIPCHK(hipSetDevice(h->d.device));
     CP_NOT_ITERATING(h);
     if (!h->linearized || !h->has_nu) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_begin before linearize / set_nu");
@@ -1292,7 +1295,8 @@ extern "C" int cp_mg_begin(cp_handle h, double theta, double tau, double sigma) 
 
 extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, int32_t world, double scale,
                            int32_t check_stop, double tol) {
-    if (!h || !h->mf || h->var || h->reg != 0 || !dev_buf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_stage");
+    if (!h || !h->mf || h->var || !dev_buf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_stage");
+    if (h->reg != 0 && stage <= CP_STAGE_EFUSED) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg fused stages need the NN-TV model");
     HIPCHK(hipSetDevice(h->d.device));
     const bool power = (stage == CP_STAGE_APPLY_A || stage == CP_STAGE_APPLY_AT);
     if (!power && !(h->it_n >= 0 && h->it_mg)) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_stage without cp_mg_begin");
@@ -1334,11 +1338,47 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             CPCHK(timer_end(h, T_EIG));
             break;
         }
+        case CP_STAGE_SPLIT_DUAL: {
+            if (n < 1 || n + 2 > h->hist_rows) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg iteration %d beyond the history capacity", n);
+            const int cur = (n - 1) & 1, nxt = n & 1;
+            CPCHK(timer_begin(h, T_DUAL));
+            launch_mf_dual<0>(h, P, h->X[cur], h->X[nxt], h->P[cur], h->P[nxt], h->W[cur], cur, nxt);
+            CPCHK(timer_end(h, T_DUAL));
+            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk, h->part, dev_buf);
+            break;
+        }
+        case CP_STAGE_SPLIT_EIG: {
+            EigArgs A = eig_args(h, P, n - 1, n, check_stop, 0, 0, tol);
+            A.nblk = world;
+            hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->W[n & 1], h->hist_p,
+                               h->hist_d);
+            break;
+        }
+        case CP_STAGE_SPLIT_PRIMAL: {
+            const int cur = (n - 1) & 1, nxt = n & 1;
+            CPCHK(timer_begin(h, T_PRIMAL));
+            launch_mf_primal<0>(h, P, h->X[cur], h->X[nxt], h->P[nxt], h->W[nxt], cur);
+            CPCHK(timer_end(h, T_PRIMAL));
+            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk, h->part, dev_buf);
+            break;
+        }
+        case CP_STAGE_SPLIT_FIN: {
+            EigArgs A = eig_args(h, P, n, n, 0, 1, n & 1, tol);
+            A.nblk = world;
+            hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->hist_p, h->hist_d);
+            break;
+        }
         case CP_STAGE_APPLY_A:
-            hipLaunchKernelGGL((k_mf_applyA<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[1], scale, h->g, h->P[1]);
+            if (h->reg == 0)
+                hipLaunchKernelGGL((k_mf_applyA<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[1], scale, h->g, h->P[1]);
+            else
+                hipLaunchKernelGGL((k_mf_applyA<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[1], scale, h->g, h->P[1]);
             break;
         case CP_STAGE_APPLY_AT:
-            hipLaunchKernelGGL((k_mf_applyAT<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->P[1], h->g, h->xtmp, h->part);
+            if (h->reg == 0)
+                hipLaunchKernelGGL((k_mf_applyAT<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->P[1], h->g, h->xtmp, h->part);
+            else
+                hipLaunchKernelGGL((k_mf_applyAT<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->P[1], h->g, h->xtmp, h->part);
             hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk, h->part, dev_buf);
             std::swap(h->X[1], h->xtmp);
             break;

@@ -102,8 +102,9 @@ EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_im
             "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start"]
 
 BUF_X0, BUF_X1, BUF_P0, BUF_P1, BUF_XTMP = 0, 1, 2, 3, 4
-SEL_ALL, SEL_X_U, SEL_P_Y12, SEL_P_DY = 0, 1, 2, 3
+SEL_ALL, SEL_X_U, SEL_P_Y12, SEL_P_DY, SEL_P_Y2 = 0, 1, 2, 3, 4
 STAGE_DUAL0, STAGE_EIG0, STAGE_FUSED, STAGE_EFUSED, STAGE_APPLY_A, STAGE_APPLY_AT = 0, 1, 2, 3, 4, 5
+STAGE_SPLIT_DUAL, STAGE_SPLIT_EIG, STAGE_SPLIT_PRIMAL, STAGE_SPLIT_FIN = 6, 7, 8, 9
 
 
 def _chk(rc):

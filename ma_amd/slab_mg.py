@@ -82,8 +82,10 @@ class SlabComm:
 
 class MultiGpuEngine:
     def __init__(self, model, m, n, k, bc, h, omega, mu, device, part, group=None):
-        if model != E.MODEL_MF_NN_TV:
-            raise E.CpEngineError("cpengine:unsupported row slabs are implemented for the NN-TV model")
+        if model not in (E.MODEL_MF_NN_TV, E.MODEL_MF_NN_CURV):
+            raise E.CpEngineError("cpengine:unsupported row slabs are implemented for the mf_nn models")
+        # NN-TV runs the fused kernel (one gather per iteration); NN-curvature the split passes (two gathers)
+        self.fused = (model == E.MODEL_MF_NN_TV)
         self.part, self.m, self.n, self.k = part, m, n, k
         self.dev = torch.device("cuda", device)
         self.comm = SlabComm(part.rank, part.world, group)
@@ -95,20 +97,22 @@ class MultiGpuEngine:
         self.red = torch.zeros(plen, **f64)
         self.gathered = torch.zeros((part.world, plen), **f64)
         self.hbuf = {}
-        for sel in (E.SEL_X_U, E.SEL_P_Y12, E.SEL_P_DY):
+        sels = (E.SEL_X_U, E.SEL_P_Y12, E.SEL_P_DY) if self.fused else (E.SEL_X_U, E.SEL_P_Y2)
+        for sel in sels:
             ln = self.eng.halo_len(sel)
-            self.hbuf[sel] = [torch.zeros(ln, **f64) for _ in range(2)]   # [send, recv]
-        self.len_xu, self.len_py = self.eng.halo_len(E.SEL_X_U), self.eng.halo_len(E.SEL_P_Y12)
-        ldy = self.eng.halo_len(E.SEL_P_DY)
-        self.s_left = torch.zeros(self.len_xu + self.len_py, **f64)     # -> left neighbour's right halo
-        self.r_right = torch.zeros(self.len_xu + self.len_py, **f64)    # <- right neighbour's first column
-        self.s_right = torch.zeros(ldy, **f64)                          # -> right neighbour's left halo
-        self.r_left = torch.zeros(ldy, **f64)                           # <- left neighbour's last column
+            self.hbuf[sel] = [torch.zeros(ln, **f64) for _ in range(4)]   # [send a, recv a, send b, recv b]
+        if self.fused:
+            self.len_xu, self.len_py = self.eng.halo_len(E.SEL_X_U), self.eng.halo_len(E.SEL_P_Y12)
+            ldy = self.eng.halo_len(E.SEL_P_DY)
+            self.s_left = torch.zeros(self.len_xu + self.len_py, **f64)     # -> left neighbour's right halo
+            self.r_right = torch.zeros(self.len_xu + self.len_py, **f64)    # <- right neighbour's first column
+            self.s_right = torch.zeros(ldy, **f64)                          # -> right neighbour's left halo
+            self.r_left = torch.zeros(ldy, **f64)                           # <- left neighbour's last column
 
     # ---- halo exchanges ---------------------------------------------------------------------------
     def _send_first_to_left(self, buf, sel):
         """first owned column -> left neighbour's right halo"""
-        send, recv = self.hbuf[sel]
+        send, recv = self.hbuf[sel][0], self.hbuf[sel][1]
         c = self.comm
         if c.left is not None:
             self.eng.halo_pack(buf, sel, 0, send.data_ptr())
@@ -118,7 +122,7 @@ class MultiGpuEngine:
 
     def _send_last_to_right(self, buf, sel):
         """last owned column -> right neighbour's left halo"""
-        send, recv = self.hbuf[sel]
+        send, recv = self.hbuf[sel][0], self.hbuf[sel][1]
         c = self.comm
         if c.right is not None:
             self.eng.halo_pack(buf, sel, 1, send.data_ptr())
@@ -126,12 +130,33 @@ class MultiGpuEngine:
         if c.left is not None:
             self.eng.halo_unpack(buf, sel, 0, recv.data_ptr())
 
+    def _exchange_both(self, buf, sel):
+        """first owned column -> left neighbour's right halo AND last owned column -> right neighbour's left halo"""
+        sl, rr, sr, rl = self.hbuf[sel]
+        c = self.comm
+        if c.left is not None:
+            self.eng.halo_pack(buf, sel, 0, sl.data_ptr())
+        if c.right is not None:
+            self.eng.halo_pack(buf, sel, 1, sr.data_ptr())
+        c.exchange(to_left=sl if c.left is not None else None, to_right=sr if c.right is not None else None,
+                   from_left=rl if c.left is not None else None, from_right=rr if c.right is not None else None)
+        if c.right is not None:
+            self.eng.halo_unpack(buf, sel, 1, rr.data_ptr())
+        if c.left is not None:
+            self.eng.halo_unpack(buf, sel, 0, rl.data_ptr())
+
     def exchange_x(self, buf):
-        self._send_first_to_left(buf, E.SEL_X_U)
+        if self.fused:
+            self._send_first_to_left(buf, E.SEL_X_U)          # forward differences: column j+1 only
+        else:
+            self._exchange_both(buf, E.SEL_X_U)               # 5-point Laplacian: columns j-1 and j+1
 
     def exchange_p(self, buf):
-        self._send_first_to_left(buf, E.SEL_P_Y12)
-        self._send_last_to_right(buf, E.SEL_P_DY)
+        if self.fused:
+            self._send_first_to_left(buf, E.SEL_P_Y12)
+            self._send_last_to_right(buf, E.SEL_P_DY)
+        else:
+            self._exchange_both(buf, E.SEL_P_Y2)
 
     def exchange_state_pack(self, xbuf, pbuf):
         """one message per neighbour and iteration: [u of x_n | y1, y2 of y_{n+1}] of the first owned column goes left,
@@ -205,7 +230,10 @@ class MultiGpuEngine:
             i += 1
             self.exchange_x(E.BUF_X1)
             self.eng.mg_stage(E.STAGE_APPLY_A, 0, self.red.data_ptr(), scale=scale)
-            self._send_last_to_right(E.BUF_P1, E.SEL_P_DY)
+            if self.fused:
+                self._send_last_to_right(E.BUF_P1, E.SEL_P_DY)
+            else:
+                self._exchange_both(E.BUF_P1, E.SEL_P_Y2)
             self.eng.mg_stage(E.STAGE_APPLY_AT, 0, self.red.data_ptr())
             s = self.red[:1].clone()
             self.comm.all_reduce_sum(s)
@@ -221,17 +249,31 @@ class MultiGpuEngine:
         eng, w = self.eng, self.part.world
         self.exchange_x(E.BUF_X0)
         self.exchange_p(E.BUF_P0)
-        eng.mg_begin(theta, tau, sigma)
-        eng.mg_stage(E.STAGE_DUAL0, 0, self.red.data_ptr())
-        self.comm.all_gather(self.gathered, self.red)
-        eng.mg_stage(E.STAGE_EIG0, 0, self.gathered.data_ptr(), world=w)
-        self.exchange_p(E.BUF_P1)
+        eng.mg_begin(theta, tau, sigma)       # x_old = x0 (halo columns included)
+        if self.fused:
+            eng.mg_stage(E.STAGE_DUAL0, 0, self.red.data_ptr())
+            self.comm.all_gather(self.gathered, self.red)
+            eng.mg_stage(E.STAGE_EIG0, 0, self.gathered.data_ptr(), world=w)
+            self.exchange_p(E.BUF_P1)
         self.it_n = 0
 
     def iterate_steps(self, iters, check_stop=0, tol=0.0):
         """`iters` more CP iterations; per iteration: fused pass, all-gather of the reduced partials, eigensolve, and
         one halo message per neighbour that is in flight during the eigensolve"""
         eng, w = self.eng, self.part.world
+        if not self.fused:
+            # split passes: dual -> gather -> eig -> halo(y2) -> primal -> gather -> fin -> halo(u)
+            for n in range(self.it_n + 1, self.it_n + iters + 1):
+                eng.mg_stage(E.STAGE_SPLIT_DUAL, n, self.red.data_ptr())
+                self.comm.all_gather(self.gathered, self.red)
+                eng.mg_stage(E.STAGE_SPLIT_EIG, n, self.gathered.data_ptr(), world=w, check_stop=check_stop, tol=tol)
+                self.exchange_p(E.BUF_P0 + (n & 1))
+                eng.mg_stage(E.STAGE_SPLIT_PRIMAL, n, self.red.data_ptr())
+                self.comm.all_gather(self.gathered, self.red)
+                eng.mg_stage(E.STAGE_SPLIT_FIN, n, self.gathered.data_ptr(), world=w)
+                self.exchange_x(E.BUF_X0 + (n & 1))
+            self.it_n += iters
+            return
         for n in range(self.it_n + 1, self.it_n + iters + 1):
             xb, pb = E.BUF_X0 + (n & 1), E.BUF_P0 + ((n + 1) & 1)
             eng.mg_stage(E.STAGE_FUSED, n, self.red.data_ptr())

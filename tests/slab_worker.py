@@ -19,13 +19,17 @@ def main():
     from ma_amd import engine as E, slab, synth
     from ma_amd.slab_mg import MultiGpuEngine
     m, n, k = 48, 44, int(os.environ.get("SLAB_K", "16"))
+    reg = os.environ.get("SLAB_REG", "tv")
+    model = E.MODEL_MF_NN_TV if reg == "tv" else E.MODEL_MF_NN_CURV
+    bc = "neumann" if reg == "tv" else os.environ.get("SLAB_BC", "dirichlet")
+    mu = 0.2 if reg == "tv" else 5.0
     iters = 14
     imgs = synth.dynamic_test_image(m, n, k).numpy()
     imgs_host = np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)])
     u0 = synth.smooth_displacement(m, n, k, amp=1.5).numpy()            # [k][2][n][m]
     omega = [0.0, float(m), 0.0, float(n)]
     part = slab.Partition(n, world, rank)
-    mg = MultiGpuEngine(E.MODEL_MF_NN_TV, m, n, k, "neumann", (1.0, 1.0), omega, 0.2, 0, part)
+    mg = MultiGpuEngine(model, m, n, k, bc, (1.0, 1.0), omega, mu, 0, part)
     mg.set_images(imgs_host)
     x0_loc = np.concatenate([u0[:, :, part.j0:part.j1, :].reshape(-1), np.zeros(k * m * part.nl)])
     mg.set_primal(x0_loc)
@@ -45,7 +49,7 @@ def main():
     dist.gather_object((part.j0, part.j1, x_loc, y_loc), xs if rank == 0 else None, dst=0)
     ok = True
     if rank == 0:
-        ref = E.Engine(E.MODEL_MF_NN_TV, m, n, k=k, bc="neumann", h=(1.0, 1.0), omega=omega, mu=0.2)
+        ref = E.Engine(model, m, n, k=k, bc=bc, h=(1.0, 1.0), omega=omega, mu=mu)
         ref.set_images(imgs_host)
         ref.set_primal(np.concatenate([u0.reshape(-1), np.zeros(k * m * n)]))
         ref.linearize()
@@ -55,12 +59,13 @@ def main():
         ref.iterate(1.0, tau, sigma, iters)
         ref.sync()
         X = ref.primal().reshape(3 * k, n, m)
-        Y = ref.dual().reshape(6 * k, n, m)
+        ny = 6 if reg == "tv" else 4
+        Y = ref.dual().reshape(ny * k, n, m)
         ref.close()
         ex = ey = 0.0
         for (j0, j1, xl, yl) in xs:
             ex = max(ex, np.abs(xl.reshape(3 * k, j1 - j0, m) - X[:, j0:j1, :]).max())
-            ey = max(ey, np.abs(yl.reshape(6 * k, j1 - j0, m) - Y[:, j0:j1, :]).max())
+            ey = max(ey, np.abs(yl.reshape(ny * k, j1 - j0, m) - Y[:, j0:j1, :]).max())
         esv = np.abs(sv - sv1).max() / sv1.max()
         print(f"slab world={world}: max|x-x1|={ex:.3e} max|y-y1|={ey:.3e} sv_rel={esv:.3e} norm {est:.15g} vs {est1:.15g} "
               f"power its {npow} vs {npow1}", flush=True)

@@ -10,9 +10,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,k", [(2, 16), (3, 5)])
-def test_slabs_match_single_gpu(world, k):
-    env = dict(os.environ, SLAB_K=str(k), MASTER_ADDR="127.0.0.1")
+@pytest.mark.parametrize("world,k,reg,bc", [(2, 16, "tv", "neumann"), (3, 5, "tv", "neumann"),
+                                            (2, 16, "curvature", "dirichlet"), (3, 4, "curvature", "neumann")])
+def test_slabs_match_single_gpu(world, k, reg, bc):
+    env = dict(os.environ, SLAB_K=str(k), SLAB_REG=reg, SLAB_BC=bc, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29400 + world), os.path.join(ROOT, "tests", "slab_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
