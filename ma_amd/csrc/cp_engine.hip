@@ -55,6 +55,8 @@ struct PassTimer {
 struct cp_engine {
     cp_problem_desc d;
     bool mf = false;     // multi-image model (mf_nn or var): K images, CpCtrl, MfParams
+    bool fp32 = false;   // CP_FLAG_FP32 (pairwise models): fields stored as float inside the double-sized allocations
+    double *stage = nullptr;   // fp32 mode: one field of doubles for host <-> device conversion
     bool var = false;    // variance model (no L block, no nuclear norm): cp_var.cuh
     int reg = 0;         // mf: 0 tv, 1 curvature
     int gt = 0;          // pairwise: GT_*
@@ -133,6 +135,22 @@ static int timer_end(cp_engine *h, int which) {
 
 // copy between the host vector layout (fields contiguous, m x nl each) and the device field layout
 static int upload_fields(cp_engine *h, double *dev, const double *host, int nfields) {
+    if (h->fp32) {   // element (f, q) lives at float index f*fs + m + q of the same allocation
+        float *devf = (float *)dev;
+        for (int f = 0; f < nfields; ++f) {
+            float *dst = devf + (size_t)f * h->fs + h->m;
+            if (host) {
+                HIPCHK(hipMemcpyAsync(h->stage, host + (size_t)f * h->npix, sizeof(double) * h->npix, hipMemcpyHostToDevice,
+                                      h->stream));
+                hipLaunchKernelGGL(k_cvt_d2f, dim3(256), dim3(256), 0, h->stream, h->npix, h->stage, dst);
+            } else {
+                HIPCHK(hipMemsetAsync(dst, 0, sizeof(float) * h->npix, h->stream));
+            }
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return CP_OK;
+    }
     for (int f = 0; f < nfields; ++f) {
         double *dst = dev + (size_t)f * h->fs + h->m;
         if (host)
@@ -145,6 +163,17 @@ static int upload_fields(cp_engine *h, double *dev, const double *host, int nfie
     return CP_OK;
 }
 static int download_fields(cp_engine *h, const double *dev, double *host, int nfields) {
+    if (h->fp32) {
+        const float *devf = (const float *)dev;
+        for (int f = 0; f < nfields; ++f) {
+            hipLaunchKernelGGL(k_cvt_f2d, dim3(256), dim3(256), 0, h->stream, h->npix, devf + (size_t)f * h->fs + h->m, h->stage);
+            HIPCHK(hipMemcpyAsync(host + (size_t)f * h->npix, h->stage, sizeof(double) * h->npix, hipMemcpyDeviceToHost,
+                                  h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        HIPCHK(hipGetLastError());
+        return CP_OK;
+    }
     for (int f = 0; f < nfields; ++f)
         HIPCHK(hipMemcpyAsync(host + (size_t)f * h->npix, dev + (size_t)f * h->fs + h->m, sizeof(double) * h->npix,
                               hipMemcpyDeviceToHost, h->stream));
@@ -182,6 +211,7 @@ extern "C" int cp_destroy(cp_handle h) {
     hipSetDevice(h->d.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->red) hipFree(h->red);
+    if (h->stage) hipFree(h->stage);
     double *ptrs[] = {h->X[0], h->X[1], h->P[0], h->P[1], h->g, h->b, h->Tu, h->img, h->imgR, h->W[0], h->W[1],
                       h->W[2], h->xtmp, h->part, h->part2, h->svout, h->hist_p, h->hist_d};
     for (double *p : ptrs)
@@ -227,6 +257,8 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         h->d.omega[3] = h->d.n_global * d.h[1];
     }
     if (pw && (h->d.n_global != d.n)) { delete h; CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported slabs for pairwise models"); }
+    if ((d.flags & CP_FLAG_FP32) && !pw) { delete h; CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported the fp32 mode covers the pairwise models"); }
+    h->fp32 = (d.flags & CP_FLAG_FP32) != 0;
     h->mf = mf;
     h->var = var;
     h->m = d.m; h->nl = d.n; h->npix = d.m * d.n; h->fs = d.m * (d.n + 2);
@@ -299,6 +331,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[2],
                                h->svout + 16 + 256);
         } else {
+            if (h->fp32) HIPCHK(hipMalloc(&h->stage, sizeof(double) * h->npix));
             HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)h->nblk * PW_PSTRIDE * h->batch));
             HIPCHK(hipMalloc(&h->part2, sizeof(double) * (size_t)h->nblk * PW_PSTRIDE * h->batch));
             HIPCHK(hipMalloc(&h->ctrl, sizeof(PwCtrl) * h->batch));
@@ -321,10 +354,7 @@ extern "C" int cp_set_images(cp_handle h, const double *a, const double *b) {
     const size_t imgN = (size_t)h->K * h->m * h->d.n_global * h->batch;
     if (!h->mf && h->gt == GT_SAD_DEN) {
         // the noisy image g plays the role of b (field layout), PDO/test_TV_L1_denoising.m:58
-        for (int pr = 0; pr < h->batch; ++pr)
-            HIPCHK(hipMemcpyAsync(h->b + (size_t)pr * h->fs + h->m, a + (size_t)pr * h->npix, sizeof(double) * h->npix,
-                                  hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        CPCHK(upload_fields(h, h->b, a, h->batch));     // one field per problem
         h->linearized = true;
     } else {
         HIPCHK(hipMemcpyAsync(h->img, a, sizeof(double) * imgN, hipMemcpyHostToDevice, h->stream));
@@ -374,12 +404,7 @@ extern "C" int cp_linearize(cp_handle h, const double *u0) {
         if (h->mf) {
             CPCHK(upload_fields(h, h->X[1], u0, nuf));
         } else {
-            for (int pr = 0; pr < h->batch; ++pr)
-                for (int f = 0; f < 2; ++f)
-                    HIPCHK(hipMemcpyAsync(h->X[1] + ((size_t)pr * h->nxf + f) * h->fs + h->m,
-                                          u0 + ((size_t)pr * 2 + f) * h->npix, sizeof(double) * h->npix,
-                                          hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            CPCHK(upload_fields(h, h->X[1], u0, 2 * h->batch));   // nxf == 2 for the registration models
         }
         xsrc = h->X[1];
     }
@@ -408,8 +433,12 @@ extern "C" int cp_linearize(cp_handle h, const double *u0) {
         W.hy = (h->d.omega[3] - h->d.omega[2]) / h->nl;
         W.inv_h1 = 1.0 / h->d.h[0]; W.inv_h2 = 1.0 / h->d.h[1];
         const int grid = (h->npix + CP_BLOCK - 1) / CP_BLOCK;
-        hipLaunchKernelGGL(k_pw_warp, dim3(grid, h->batch), dim3(CP_BLOCK), 0, h->stream, W, h->img, h->imgR, xsrc,
-                           h->Tu, h->g, h->b);
+        if (h->fp32)
+            hipLaunchKernelGGL((k_pw_warp<float>), dim3(grid, h->batch), dim3(CP_BLOCK), 0, h->stream, W, h->img, h->imgR,
+                               (const float *)xsrc, (float *)h->Tu, (float *)h->g, (float *)h->b);
+        else
+            hipLaunchKernelGGL((k_pw_warp<double>), dim3(grid, h->batch), dim3(CP_BLOCK), 0, h->stream, W, h->img, h->imgR,
+                               xsrc, h->Tu, h->g, h->b);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -859,30 +888,43 @@ static int solve_mf(cp_engine *h, double theta, double tau, double sigma, int ma
 }
 
 // ------------------------------------------------------------------------------------------------
+template <typename S, int MODE>
+static void launch_pw_dual_t(cp_engine *h, const PwParams &P, const double *xc, const double *xo, const double *vin,
+                             double *vout) {
+    dim3 grid(h->nblk, h->batch);
+    if (h->nc == 2)
+        hipLaunchKernelGGL((k_pw_dual<S, MODE, 2>), grid, dim3(CP_BLOCK), 0, h->stream, P, (const S *)xc, (const S *)xo,
+                           (const S *)vin, (S *)vout, (const PwCtrl *)h->ctrl, h->part);
+    else
+        hipLaunchKernelGGL((k_pw_dual<S, MODE, 1>), grid, dim3(CP_BLOCK), 0, h->stream, P, (const S *)xc, (const S *)xo,
+                           (const S *)vin, (S *)vout, (const PwCtrl *)h->ctrl, h->part);
+}
 template <int MODE>
 static void launch_pw_dual(cp_engine *h, const PwParams &P, const double *xc, const double *xo, const double *vin,
                            double *vout) {
+    if (h->fp32) launch_pw_dual_t<float, MODE>(h, P, xc, xo, vin, vout);
+    else launch_pw_dual_t<double, MODE>(h, P, xc, xo, vin, vout);
+}
+template <typename S, int MODE>
+static void launch_pw_primal_t(cp_engine *h, const PwParams &P, const double *xc_, double *xn_, const double *v_) {
     dim3 grid(h->nblk, h->batch);
-    if (h->nc == 2)
-        hipLaunchKernelGGL((k_pw_dual<MODE, 2>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xo, vin, vout,
-                           (const PwCtrl *)h->ctrl, h->part);
+    const PwCtrl *ctrl = (const PwCtrl *)h->ctrl;
+    const S *xc = (const S *)xc_, *v = (const S *)v_, *g = (const S *)h->g, *b = (const S *)h->b;
+    S *xn = (S *)xn_;
+    if (h->gt == GT_SAD_REG)
+        hipLaunchKernelGGL((k_pw_primal<S, MODE, GT_SAD_REG>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xn, v, g, b, ctrl,
+                           h->part2);
+    else if (h->gt == GT_SSD_REG)
+        hipLaunchKernelGGL((k_pw_primal<S, MODE, GT_SSD_REG>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xn, v, g, b, ctrl,
+                           h->part2);
     else
-        hipLaunchKernelGGL((k_pw_dual<MODE, 1>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xo, vin, vout,
-                           (const PwCtrl *)h->ctrl, h->part);
+        hipLaunchKernelGGL((k_pw_primal<S, MODE, GT_SAD_DEN>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xn, v, b, b, ctrl,
+                           h->part2);
 }
 template <int MODE>
 static void launch_pw_primal(cp_engine *h, const PwParams &P, const double *xc, double *xn, const double *v) {
-    dim3 grid(h->nblk, h->batch);
-    const PwCtrl *ctrl = (const PwCtrl *)h->ctrl;
-    if (h->gt == GT_SAD_REG)
-        hipLaunchKernelGGL((k_pw_primal<MODE, GT_SAD_REG>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xn, v, h->g, h->b,
-                           ctrl, h->part2);
-    else if (h->gt == GT_SSD_REG)
-        hipLaunchKernelGGL((k_pw_primal<MODE, GT_SSD_REG>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xn, v, h->g, h->b,
-                           ctrl, h->part2);
-    else
-        hipLaunchKernelGGL((k_pw_primal<MODE, GT_SAD_DEN>), grid, dim3(CP_BLOCK), 0, h->stream, P, xc, xn, v, h->b, h->b,
-                           ctrl, h->part2);
+    if (h->fp32) launch_pw_primal_t<float, MODE>(h, P, xc, xn, v);
+    else launch_pw_primal_t<double, MODE>(h, P, xc, xn, v);
 }
 static PwFinArgs pw_fin_args(const cp_engine *h, int rpF, int rpG, int rd, int check, double tol) {
     PwFinArgs A;
@@ -951,10 +993,12 @@ static int solve_pw(cp_engine *h, double theta, double tau, double sigma, int ma
         const int it = hc[pr].stop ? hc[pr].stop_iter : maxIter;
         h->last[pr] = cp_result{it, hc[pr].stop ? CP_STOP_TOLERANCE : CP_STOP_MAXITER, it + 1, h->hcols};
         if (it & 1) {
-            HIPCHK(hipMemcpyAsync(h->X[0] + (size_t)pr * h->nxf * h->fs, h->X[1] + (size_t)pr * h->nxf * h->fs,
-                                  sizeof(double) * h->nxf * h->fs, hipMemcpyDeviceToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(h->P[0] + (size_t)pr * h->npf * h->fs, h->P[1] + (size_t)pr * h->npf * h->fs,
-                                  sizeof(double) * h->npf * h->fs, hipMemcpyDeviceToDevice, h->stream));
+            const size_t esz = h->fp32 ? sizeof(float) : sizeof(double);
+            const size_t xo = (size_t)pr * h->nxf * h->fs * esz, po = (size_t)pr * h->npf * h->fs * esz;
+            HIPCHK(hipMemcpyAsync((char *)h->X[0] + xo, (char *)h->X[1] + xo, esz * h->nxf * h->fs, hipMemcpyDeviceToDevice,
+                                  h->stream));
+            HIPCHK(hipMemcpyAsync((char *)h->P[0] + po, (char *)h->P[1] + po, esz * h->npf * h->fs, hipMemcpyDeviceToDevice,
+                                  h->stream));
         }
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1022,6 +1066,7 @@ extern "C" int cp_prolong(cp_handle coarse, cp_handle fine, double factor) {
     HIPCHK(hipSetDevice(fine->d.device));
     CP_NOT_ITERATING(coarse);
     CP_NOT_ITERATING(fine);
+    if (coarse->fp32 || fine->fp32) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_prolong in fp32 mode");
     HIPCHK(hipStreamSynchronize(coarse->stream));
     const int nf = fine->nxf * fine->batch;
     hipLaunchKernelGGL(k_prolong, dim3(2048), dim3(CP_BLOCK), 0, fine->stream, fine->m, fine->nl, fine->fs, coarse->m,

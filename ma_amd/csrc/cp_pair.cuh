@@ -26,18 +26,20 @@ struct PwParams {
 #define PW_NM 2
 #define PW_PSTRIDE (PW_NS + PW_NM)
 
-template <int MODE, int NC>
-__global__ __launch_bounds__(CP_BLOCK) void k_pw_dual(PwParams P, const double *__restrict__ xc_,
-                                                      const double *__restrict__ xo_,
-                                                      const double *__restrict__ vin_, double *__restrict__ vout_,
+// S = storage type of the state and linearisation fields (double, or float in CP_FLAG_FP32 mode); arithmetic, partial
+// sums and histories are fp64 either way, so the fp32 mode halves the HBM traffic and nothing else.
+template <typename S, int MODE, int NC>
+__global__ __launch_bounds__(CP_BLOCK) void k_pw_dual(PwParams P, const S *__restrict__ xc_,
+                                                      const S *__restrict__ xo_,
+                                                      const S *__restrict__ vin_, S *__restrict__ vout_,
                                                       const PwCtrl *__restrict__ ctrl, double *__restrict__ part) {
     __shared__ double red[CP_WAVES * PW_PSTRIDE];
     const int prob = blockIdx.y;
     if (ctrl[prob].stop) return;
     const int m = P.m, fs = P.fs;
-    const double *xc = xc_ + (size_t)prob * P.nxf * fs, *xo = xo_ + (size_t)prob * P.nxf * fs;
-    const double *vin = vin_ + (size_t)prob * P.nvf * fs;
-    double *vout = vout_ + (size_t)prob * P.nvf * fs;
+    const S *xc = xc_ + (size_t)prob * P.nxf * fs, *xo = xo_ + (size_t)prob * P.nxf * fs;
+    const S *vin = vin_ + (size_t)prob * P.nvf * fs;
+    S *vout = vout_ + (size_t)prob * P.nvf * fs;
     const double sigma = P.sigma, theta = P.theta;
     double sums[PW_NS] = {0.0, 0.0}, maxs[PW_NM] = {0.0, 0.0};
     for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_dual(PwParams P, const double *
         double dcur[2 * NC], dbar[2 * NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const double *uc = xc + (size_t)c * fs + e, *uo = xo + (size_t)c * fs + e;
+            const S *uc = xc + (size_t)c * fs + e, *uo = xo + (size_t)c * fs + e;
             const double u0 = uc[0], ub0 = u0 + theta * (u0 - uo[0]);              // chambolle_pock.m:179
             double ui = 0.0, ubi = 0.0, uj = 0.0, ubj = 0.0;
             if (!last_i) { ui = uc[1]; ubi = ui + theta * (ui - uo[1]); }
@@ -75,8 +77,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_dual(PwParams P, const double *
             nn2 = 0.0;
 #pragma unroll
             for (int c = 0; c < 2 * NC; ++c) {
-                vn[c] = vn[c] / den;
-                vout[(size_t)c * fs + e] = vn[c];
+                vn[c] = (double)(S)(vn[c] / den);          // the stored (rounded) value is the iterate
+                vout[(size_t)c * fs + e] = (S)vn[c];
                 nn2 += vn[c] * vn[c];
             }
             nrm = sqrt(nn2);
@@ -87,20 +89,20 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_dual(PwParams P, const double *
                                      part + ((size_t)prob * gridDim.x + blockIdx.x) * PW_PSTRIDE);
 }
 
-template <int MODE, int GT>
-__global__ __launch_bounds__(CP_BLOCK) void k_pw_primal(PwParams P, const double *__restrict__ xc_,
-                                                        double *__restrict__ xn_, const double *__restrict__ v_,
-                                                        const double *__restrict__ g_, const double *__restrict__ b_,
+template <typename S, int MODE, int GT>
+__global__ __launch_bounds__(CP_BLOCK) void k_pw_primal(PwParams P, const S *__restrict__ xc_,
+                                                        S *__restrict__ xn_, const S *__restrict__ v_,
+                                                        const S *__restrict__ g_, const S *__restrict__ b_,
                                                         const PwCtrl *__restrict__ ctrl, double *__restrict__ part) {
     __shared__ double red[CP_WAVES * PW_PSTRIDE];
     constexpr int NC = (GT == GT_SAD_DEN) ? 1 : 2;
     const int prob = blockIdx.y;
     if (ctrl[prob].stop) return;
     const int m = P.m, fs = P.fs;
-    const double *xc = xc_ + (size_t)prob * P.nxf * fs;
-    double *xn = xn_ + (size_t)prob * P.nxf * fs;
-    const double *v = v_ + (size_t)prob * P.nvf * fs;
-    const double *g = g_ + (size_t)prob * 2 * fs, *b = b_ + (size_t)prob * fs;
+    const S *xc = xc_ + (size_t)prob * P.nxf * fs;
+    S *xn = xn_ + (size_t)prob * P.nxf * fs;
+    const S *v = v_ + (size_t)prob * P.nvf * fs;
+    const S *g = g_ + (size_t)prob * 2 * fs, *b = b_ + (size_t)prob * fs;
     const double tau = P.tau, lam = P.lambda, lt = P.lambda * P.tau;
     double sums[PW_NS] = {0.0, 0.0}, maxs[PW_NM] = {0.0, 0.0};
     for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_primal(PwParams P, const double
         double w[NC], ut[NC], un[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const double *fx = v + (size_t)(2 * c) * fs + e, *fy = v + (size_t)(2 * c + 1) * fs + e;
+            const S *fx = v + (size_t)(2 * c) * fs + e, *fy = v + (size_t)(2 * c + 1) * fs + e;
             const double ax = fwd_diff_adj(fx[0], (i >= 1) ? fx[-1] : 0.0, 0.0, i, m, false, P.inv_h1);
             const double ay = fwd_diff_adj(fy[0], (j >= 1) ? fy[-m] : 0.0, 0.0, j, P.n, false, P.inv_h2);
             w[c] = ax + ay;                                                         // (K'v)_c
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_primal(PwParams P, const double
                 else if (ngs > 1e-14) { const double r = phi / ngs; un[0] = ut[0] - gx * r; un[NC - 1] = ut[NC - 1] - gy * r; }
                 else { un[0] = ut[0]; un[NC - 1] = ut[NC - 1]; }                    // :58-76
             }
+            if (MODE == 0 && sizeof(S) == 4) { un[0] = (double)(S)un[0]; un[NC - 1] = (double)(S)un[NC - 1]; }
             sums[0] += fabs(bb + (gx * un[0] + gy * un[NC - 1]));                   // :47
             // conjugate at -K'v, scaled by 1/lambda  (:86-138)
             const double zx = -w[0] / lam, zy = -w[NC - 1] / lam;
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_primal(PwParams P, const double
                 un[0] = (a22 * cx - a12 * cy) / det;
                 un[NC - 1] = (a11 * cy - a12 * cx) / det;
             }
+            if (MODE == 0 && sizeof(S) == 4) { un[0] = (double)(S)un[0]; un[NC - 1] = (double)(S)un[NC - 1]; }
             const double res = (gx * un[0] + gy * un[NC - 1]) + bb;
             sums[0] += res * res;                                                   // :50-51
             const double zx = -w[0] / lam, zy = -w[NC - 1] / lam;                   // :70
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_primal(PwParams P, const double
                 const double d = ut[0] - gi;                                        // SAD_denoise.m:46-52
                 un[0] = (d > lam * tau) ? ut[0] - lam * tau : ((d < (-1.0) * lam * tau) ? ut[0] + lam * tau : gi);
             }
+            if (MODE == 0 && sizeof(S) == 4) un[0] = (double)(S)un[0];
             sums[0] += fabs(un[0] - gi);                                            // :40
             const double z = -w[0] / lam;                                           // :60
             sums[1] += z * gi;                                                      // :66
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_primal(PwParams P, const double
         }
         if (MODE == 0) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) xn[(size_t)c * fs + e] = un[c];
+            for (int c = 0; c < NC; ++c) xn[(size_t)c * fs + e] = (S)un[c];
         }
     }
     block_reduce_store<PW_NS, PW_NM>(sums, maxs, red,
@@ -272,22 +277,33 @@ struct PwWarpParams {
     int m, n, npix, fs, nxf;
     double hx, hy, inv_h1, inv_h2;
 };
+template <typename S>
 __global__ __launch_bounds__(CP_BLOCK) void k_pw_warp(PwWarpParams P, const double *__restrict__ T_,
-                                                      const double *__restrict__ R_, const double *__restrict__ x_,
-                                                      double *__restrict__ Tu_, double *__restrict__ g_,
-                                                      double *__restrict__ b_) {
+                                                      const double *__restrict__ R_, const S *__restrict__ x_,
+                                                      S *__restrict__ Tu_, S *__restrict__ g_,
+                                                      S *__restrict__ b_) {
     const int prob = blockIdx.y;
     const int q = blockIdx.x * CP_BLOCK + threadIdx.x;
     if (q >= P.npix) return;
     const int j = q / P.m, i = q - j * P.m, e = q + P.m;
-    const double *x = x_ + (size_t)prob * P.nxf * P.fs;
+    const S *x = x_ + (size_t)prob * P.nxf * P.fs;
     const double ux = x[e], uy = x[(size_t)P.fs + e];
     const double px = __dadd_rn(__dadd_rn(0.0, __dmul_rn(P.hx, (double)i + 0.5)), ux);
     const double py = __dadd_rn(__dadd_rn(0.0, __dmul_rn(P.hy, (double)j + 0.5)), uy);
     double val, dx, dy;
     bilinear_tap(T_ + (size_t)prob * P.npix, P.m, P.n, px, py, P.inv_h1, P.inv_h2, val, dx, dy);
-    Tu_[(size_t)prob * P.fs + e] = val;
-    g_[(size_t)prob * 2 * P.fs + e] = dx;
-    g_[(size_t)prob * 2 * P.fs + P.fs + e] = dy;
-    b_[(size_t)prob * P.fs + e] = val - (dx * ux + dy * uy) - R_[(size_t)prob * P.npix + q];
+    // the stored (rounded) gradient is the one the iteration uses, so b is formed from it
+    const double dxs = (double)(S)dx, dys = (double)(S)dy;
+    Tu_[(size_t)prob * P.fs + e] = (S)val;
+    g_[(size_t)prob * 2 * P.fs + e] = (S)dx;
+    g_[(size_t)prob * 2 * P.fs + P.fs + e] = (S)dy;
+    b_[(size_t)prob * P.fs + e] = (S)(val - (dxs * ux + dys * uy) - R_[(size_t)prob * P.npix + q]);
+}
+
+// host double <-> device float field conversion (fp32 mode transfers)
+__global__ void k_cvt_d2f(int n, const double *__restrict__ src, float *__restrict__ dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+__global__ void k_cvt_f2d(int n, const float *__restrict__ src, double *__restrict__ dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = (double)src[i];
 }

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("CP_ENGINE_LIB", os.path.join(_HERE, "libcpengine.so")
 MODEL_TV_L1_DENOISE, MODEL_TV_L1_REG, MODEL_TV_L2_REG, MODEL_MF_NN_TV, MODEL_MF_NN_CURV = 1, 2, 3, 4, 5
 MODEL_VAR_TV, MODEL_VAR_CURV = 6, 7
 FLAG_VAR_SSD_SWAP = 1
+FLAG_FP32 = 2
 BC = {"neumann": 0, "linear": 1, "dirichlet": 2}
 STOP_MAXITER, STOP_TOLERANCE = 0, 1
 

@@ -28,9 +28,10 @@ if "c5" in which:
     m = n = 512; B = 256
     fr = synth.dynamic_test_image(m, n, 2).numpy()
     T = np.tile(fr[1].reshape(-1, order="F"), B); R = np.tile(fr[0].reshape(-1, order="F"), B)
-    eng = E.Engine(E.MODEL_TV_L2_REG, m, n, lam=50.0, batch=B)
-    eng.set_images(T, R); eng.set_primal(np.zeros(2*m*n*B)); eng.linearize()
-    tau = 4.0; run("C5 TV-L2 256 x 512^2", eng, 1.0, tau, (1 - 1e-4) / (8 * tau), 100, 23 * 8.0 * m * n * B); eng.close()
+    for tag, flags, esz in (("fp64", 0, 8.0), ("fp32", E.FLAG_FP32, 4.0)):
+        eng = E.Engine(E.MODEL_TV_L2_REG, m, n, lam=50.0, batch=B, flags=flags)
+        eng.set_images(T, R); eng.set_primal(np.zeros(2*m*n*B)); eng.linearize()
+        tau = 4.0; run(f"C5 TV-L2 256 x 512^2 {tag}", eng, 1.0, tau, (1 - 1e-4) / (8 * tau), 100, 23 * esz * m * n * B); eng.close()
 for tag, model, el, mu in (("c4", E.MODEL_MF_NN_CURV, 31, 20.0), ("var", E.MODEL_VAR_TV, 28, 0.1)):
     if tag not in which: continue
     m = n = 4096; k = 16
