@@ -56,6 +56,7 @@ struct cp_engine {
     cp_problem_desc d;
     bool mf = false;     // multi-image model (mf_nn or var): K images, CpCtrl, MfParams
     bool fp32 = false;   // CP_FLAG_FP32 (pairwise models): fields stored as float inside the double-sized allocations
+    double *vwarm = nullptr;   // NN-TV: eigenvector bases of the previous iteration (2 x 256), warm start of k_mf_efused
     double *stage = nullptr;   // fp32 mode: one field of doubles for host <-> device conversion
     bool var = false;    // variance model (no L block, no nuclear norm): cp_var.cuh
     int reg = 0;         // mf: 0 tv, 1 curvature
@@ -212,6 +213,7 @@ extern "C" int cp_destroy(cp_handle h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->red) hipFree(h->red);
     if (h->stage) hipFree(h->stage);
+    if (h->vwarm) hipFree(h->vwarm);
     double *ptrs[] = {h->X[0], h->X[1], h->P[0], h->P[1], h->g, h->b, h->Tu, h->img, h->imgR, h->W[0], h->W[1],
                       h->W[2], h->xtmp, h->part, h->part2, h->svout, h->hist_p, h->hist_d};
     for (double *p : ptrs)
@@ -325,6 +327,8 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             HIPCHK(hipMalloc(&h->part2, sizeof(double) * (size_t)(CP_FUSED_MAXGRID / CP_S1_GROUP) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->svout, sizeof(double) * (16 + 256 + 256)));
             HIPCHK(hipMalloc(&h->red, sizeof(double) * CP_PSTRIDE));
+            HIPCHK(hipMalloc(&h->vwarm, sizeof(double) * 512));
+            HIPCHK(hipMemsetAsync(h->vwarm, 0, sizeof(double) * 512, h->stream));
             HIPCHK(hipMalloc(&h->ctrl, sizeof(CpCtrl)));
             HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(CpCtrl), h->stream));
             hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1]);
@@ -676,6 +680,10 @@ static const double *fused_partials(cp_engine *h, int *rows) {
     return h->part2;
 }
 
+// warm start of the eigensolves from the previous iteration's bases; a cold start every 32 iterations (and at the first
+// one) keeps the accumulated product of rotations orthogonal to rounding
+static inline int efused_warm(int n) { return (n > 1 && (n & 31) != 1) ? 1 : 0; }
+
 // ---- fused NN-TV path: F_0 = dual step 1 alone, then one k_mf_fused_tv + k_mf_efused per iteration -------------
 static int mf_fused_start(cp_engine *h, const MfParams &P, double tol) {
     CpCtrl *ctrl = (CpCtrl *)h->ctrl;
@@ -699,10 +707,11 @@ static int mf_fused_iterations(cp_engine *h, const MfParams &P, int n0, int coun
         EFusedArgs A;
         A.K = h->K; A.n = n; A.check_stop = check; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
         A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot;
+        A.warm = efused_warm(n);
         CPCHK(timer_begin(h, T_EIG));
         const double *rows = fused_partials(h, &A.nblk);
         hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, rows, ctrl, h->W[nxt], h->hist_p,
-                           h->hist_d);
+                           h->hist_d, h->vwarm);
         CPCHK(timer_end(h, T_EIG));
     }
     HIPCHK(hipGetLastError());
@@ -1377,9 +1386,10 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             EFusedArgs A;
             A.nblk = world; A.K = h->K; A.n = n; A.check_stop = check_stop; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
             A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot;
+            A.warm = efused_warm(n);
             CPCHK(timer_begin(h, T_EIG));
             hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->W[(n + 1) & 1],
-                               h->hist_p, h->hist_d);
+                               h->hist_p, h->hist_d, h->vwarm);
             CPCHK(timer_end(h, T_EIG));
             break;
         }

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
 }
 
 struct EFusedArgs {
+    int warm;            // start both eigensolves from the previous iteration's eigenvectors (vwarm)
     int nblk, K;
     int n;               // iteration: completes primal row n and dual row n, starts dual row n+1
     int check_stop;
@@ -269,9 +270,11 @@ struct EFusedArgs {
 
 __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, const double *__restrict__ part,
                                                               CpCtrl *ctrl, double *__restrict__ Wout, double *hist_p,
-                                                              double *hist_d) {
-    __shared__ double G[16][17], V[16][17], G2[16][17], G2h[16][17], sc[CP_NSCAL], cs[2][8][2], dvec[16],
-        stage[CP_RED_THREADS];
+                                                              double *hist_d, double *__restrict__ vwarm) {
+    // GG[0] = Gram(y3~), GG[1] = deflated Gram(B*L); VV: accumulated rotations; V0: warm-start bases; Tm: scratch
+    __shared__ double GG[2][16][17], VV[2][16][17], V0[2][16][17], Tm[2][16][17], G2[16][17], sc[CP_NSCAL], cs[2][8][2],
+        dvec[16], stage[CP_RED_THREADS];
+    double (*G)[17] = GG[0], (*V)[17] = VV[0], (*G2h)[17] = GG[1];
     __shared__ int pq[2][8][2], rotflag[2];
     __shared__ double res[4];   // spmax, con3
     if (ctrl->stop) return;
@@ -297,7 +300,34 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
     }
     if (t >= 512) return;        // the eigensolves need 2 x 256 threads; ended waves do not take part in barriers
     __syncthreads();
-    jacobi16_pair(G, V, G2h, cs, pq, rotflag);
+    {
+        // The Gram matrices change little from one iteration to the next: rotate them into the previous
+        // eigenvector bases first (G' = V0' G V0 is then almost diagonal and needs 2-3 sweeps instead of ~8).
+        const int mid = t >> 8, tl = t & 255, r = tl >> 4, c = tl & 15;
+        VV[mid][r][c] = (r == c) ? 1.0 : 0.0;
+        if (A.warm) {
+            V0[mid][r][c] = vwarm[mid * 256 + tl];
+            __syncthreads();
+            double acc = 0.0;
+            for (int i = 0; i < 16; ++i) acc += GG[mid][r][i] * V0[mid][i][c];
+            Tm[mid][r][c] = acc;
+            __syncthreads();
+            acc = 0.0;
+            for (int i = 0; i < 16; ++i) acc += V0[mid][i][r] * Tm[mid][i][c];
+            __syncthreads();
+            GG[mid][r][c] = acc;
+        }
+        __syncthreads();
+        jacobi16_pair(GG, VV, cs, pq, rotflag);
+        if (A.warm) {   // eigenvectors in the original basis: V0 * V
+            double acc = 0.0;
+            for (int i = 0; i < 16; ++i) acc += V0[mid][r][i] * VV[mid][i][c];
+            __syncthreads();
+            VV[mid][r][c] = acc;
+        }
+        vwarm[mid * 256 + tl] = (A.warm) ? VV[mid][r][c] : VV[mid][r][c];
+        __syncthreads();
+    }
     if (t == 0) {
         const int K = A.K;
         const double nu = ctrl->nu, mu_ = nu * A.sigma;   // NNE/nuclear_norm_constraint.m:72

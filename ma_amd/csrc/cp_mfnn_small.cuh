@@ -133,38 +133,44 @@ __device__ void jacobi16(double (*G)[17], double (*V)[17], double (*cs)[2], int 
     }
 }
 
-// Two independent symmetric 16 x 16 eigenproblems side by side: threads 0..255 work on (G0, V0), threads 256..511 on G1
-// (eigenvalues only). Same rotations per matrix as jacobi16 (a converged matrix only sees identity rotations), half the
-// barrier phases of two calls in a row. Call with exactly 512 live threads.
-__device__ void jacobi16_pair(double (*G0)[17], double (*V0)[17], double (*G1)[17], double (*cs)[8][2], int (*pq)[8][2],
-                              int *rotflag) {
+// Two independent symmetric 16 x 16 eigenproblems side by side: threads 0..255 work on (G[0], V[0]), threads 256..511 on
+// (G[1], V[1]). Same rotations per matrix as jacobi16; a sweep starts only if some off-diagonal entry still exceeds the
+// rotation threshold (a sweep without rotations would be a no-op). V must be initialised by the caller (identity, or
+// anything orthogonal: the rotations are accumulated onto it). Call with exactly 512 live threads.
+__device__ void jacobi16_pair(double (*G)[16][17], double (*V)[16][17], double (*cs)[8][2], int (*pq)[8][2], int *rotflag) {
     const int t = threadIdx.x, mid = t >> 8, tl = t & 255;
-    double (*G)[17] = mid ? G1 : G0;
-    if (mid == 0) V0[tl >> 4][tl & 15] = ((tl >> 4) == (tl & 15)) ? 1.0 : 0.0;
+    double (*Gm)[17] = G[mid];
+    double (*Vm)[17] = V[mid];
     {
         const int r = tl >> 4, c = tl & 15;
-        const double s = 0.5 * (G[r][c] + G[c][r]);
+        const double s = 0.5 * (Gm[r][c] + Gm[c][r]);
         __syncthreads();
-        G[r][c] = s;
+        Gm[r][c] = s;
     }
     __syncthreads();
     for (int sweep = 0; sweep < 30; ++sweep) {
         if (tl == 0) rotflag[mid] = 0;
         __syncthreads();
+        {
+            const int r = tl >> 4, c = tl & 15;
+            const double apq = Gm[r][c];
+            if (r < c && fabs(apq) > 1.0e-17 * sqrt(fabs(Gm[r][r] * Gm[c][c])) && fabs(apq) > 1.0e-300) rotflag[mid] = 1;
+        }
+        __syncthreads();
+        if (rotflag[0] == 0 && rotflag[1] == 0) break;
         for (int r = 0; r < 15; ++r) {
             if (tl < 8) {
                 int p, q;
                 if (tl == 0) { p = 15; q = r; }
                 else { p = (r + tl) % 15; q = (r - tl + 15) % 15; }
                 if (p > q) { const int tmp = p; p = q; q = tmp; }
-                const double app = G[p][p], aqq = G[q][q], apq = G[p][q];
+                const double app = Gm[p][p], aqq = Gm[q][q], apq = Gm[p][q];
                 double c = 1.0, s = 0.0;
                 if (fabs(apq) > 1.0e-17 * sqrt(fabs(app * aqq)) && fabs(apq) > 1.0e-300) {
                     const double th = (aqq - app) / (2.0 * apq);
                     const double tt = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
                     c = 1.0 / sqrt(tt * tt + 1.0);
                     s = tt * c;
-                    rotflag[mid] = 1;
                 }
                 cs[mid][tl][0] = c; cs[mid][tl][1] = s; pq[mid][tl][0] = p; pq[mid][tl][1] = q;
             }
@@ -174,13 +180,13 @@ __device__ void jacobi16_pair(double (*G0)[17], double (*V0)[17], double (*G1)[1
                 const int p = pq[mid][pi][0], q = pq[mid][pi][1];
                 const double c = cs[mid][pi][0], s = cs[mid][pi][1];
                 if (tl < 128) {
-                    const double gp = G[l][p], gq = G[l][q];
-                    G[l][p] = c * gp - s * gq;
-                    G[l][q] = s * gp + c * gq;
-                } else if (mid == 0) {
-                    const double vp = V0[l][p], vq = V0[l][q];
-                    V0[l][p] = c * vp - s * vq;
-                    V0[l][q] = s * vp + c * vq;
+                    const double gp = Gm[l][p], gq = Gm[l][q];
+                    Gm[l][p] = c * gp - s * gq;
+                    Gm[l][q] = s * gp + c * gq;
+                } else {
+                    const double vp = Vm[l][p], vq = Vm[l][q];
+                    Vm[l][p] = c * vp - s * vq;
+                    Vm[l][q] = s * vp + c * vq;
                 }
             }
             __syncthreads();
@@ -188,15 +194,12 @@ __device__ void jacobi16_pair(double (*G0)[17], double (*V0)[17], double (*G1)[1
                 const int pi = tl >> 4, l = tl & 15;
                 const int p = pq[mid][pi][0], q = pq[mid][pi][1];
                 const double c = cs[mid][pi][0], s = cs[mid][pi][1];
-                const double gp = G[p][l], gq = G[q][l];
-                G[p][l] = c * gp - s * gq;
-                G[q][l] = s * gp + c * gq;
+                const double gp = Gm[p][l], gq = Gm[q][l];
+                Gm[p][l] = c * gp - s * gq;
+                Gm[q][l] = s * gp + c * gq;
             }
             __syncthreads();
         }
-        const int done = (rotflag[0] == 0) && (rotflag[1] == 0);
-        __syncthreads();
-        if (done) break;
     }
 }
 

@@ -17,8 +17,10 @@ def test_create_errors():
         E.Engine(99, 16, 16)
     with pytest.raises(E.CpEngineError, match="badArg"):
         E.Engine(E.MODEL_TV_L1_REG, 16, 16, h=(0.0, 1.0))
-    with pytest.raises(E.CpEngineError, match="unsupported"):    # slabs: NN-TV + neumann only
-        E.Engine(E.MODEL_MF_NN_CURV, 16, 8, k=3, n_global=16, j_offset=0)
+    with pytest.raises(E.CpEngineError, match="unsupported"):    # slabs: no linear boundary row, no variance models
+        E.Engine(E.MODEL_MF_NN_TV, 16, 8, k=3, bc="linear", n_global=16, j_offset=0)
+    with pytest.raises(E.CpEngineError, match="unsupported"):
+        E.Engine(E.MODEL_VAR_TV, 16, 8, k=3, n_global=16, j_offset=0)
     with pytest.raises(E.CpEngineError, match="badArg"):
         E.Engine(E.MODEL_MF_NN_TV, 16, 8, k=3, n_global=12, j_offset=8)
 

@@ -145,3 +145,32 @@ def test_extreme_shapes(reg, bc, m, n, k):
     np.testing.assert_allclose(ph[:, 5:], phr[:, 5:], rtol=0, atol=1e-6)
     np.testing.assert_allclose(dh[:, 5:], dhr[:, 5:], rtol=0, atol=1e-8)
     assert _rel(x, xr) < TOL and _rel(y, yr) < TOL
+
+
+def test_long_run_against_c_restatement():
+    """300 iterations (warm-started eigensolves with periodic cold restarts, lazy W, predicted means) stay within the
+    north_star tolerance of the C restatement"""
+    from ma_amd import engine as E
+    from oracle import c_oracle
+    m, n, k = 96, 80, 16
+    imgs, u0, omega, h, A, b, T_u, gs = _setup(m, n, k, "tv", "neumann")
+    mu, nu, tau, sigma = 0.2, 1.2 * k, 0.3, 0.3
+    kmn = k * m * n
+    x0 = np.concatenate([u0.reshape(-1), 0.5 * T_u.reshape(-1, order="F")])
+    y0 = np.zeros(6 * kmn)
+    g = np.concatenate([gs[i].reshape(-1, order="F") for i in range(k)])
+    iters = 300
+    xr, yr, phr, dhr = c_oracle.nntv_chambolle_pock(m, n, k, "neumann", h, mu, nu, 1.0, tau, sigma, iters, None, g, b, x0, y0)
+    eng = E.Engine(E.MODEL_MF_NN_TV, m, n, k=k, bc="neumann", h=h, omega=omega, mu=mu)
+    eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+    eng.set_primal(x0)
+    eng.linearize()
+    eng.set_nu(nu)
+    eng.solve(1.0, tau, sigma, iters, 0.0)
+    x, y = eng.primal(), eng.dual()
+    ph, dh = eng.history()
+    eng.close()
+    assert ph.shape == phr.shape == (iters + 1, 7)
+    np.testing.assert_allclose(ph[:, 0], phr[:, 0], rtol=1e-10)
+    np.testing.assert_allclose(dh[:, 0], dhr[:, 0], rtol=1e-10)
+    assert _rel(x, xr) < TOL and _rel(y, yr) < TOL
