@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--reg", default="tv", choices=["tv", "curvature"])
+    ap.add_argument("--fp32", action="store_true", help="CP_FLAG_FP32 storage mode (single GPU); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=1024)
     ap.add_argument("--cpu-iters", type=int, default=40)
@@ -144,7 +145,8 @@ def main():
     # NN-TV: bc neumann, mu 0.2 (headline); NN-curvature: bc dirichlet, mu 20
     bc, mu = ("neumann", 0.2) if reg == "tv" else ("dirichlet", 20.0)
     solver = slab.SlabSolver(model, m, n, k, bc=bc, h=(1.0, 1.0), omega=[0.0, float(m), 0.0, float(n)],
-                             mu=mu, device=local_rank, part=part)
+                             mu=mu, device=local_rank, part=part, flags=E.FLAG_FP32 if args.fp32 else 0)
+    esz = 4.0 if args.fp32 else 8.0                            # bytes per stored element
     solver.set_images(imgs_host)
     del imgs_host
     # x0 = [u0; L0 = 0]; p0 = 0
@@ -193,21 +195,21 @@ def main():
         traffic = None
         try:
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
-            if prof and reg == "tv" and m == 4096 and k == 16 and world == 1:
+            if prof and reg == "tv" and m == 4096 and k == 16 and world == 1 and not args.fp32:
                 traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))["hbm_bytes_per_launch"] / 1e9
         except Exception:
             traffic = None
         kmn_total = float(k) * m * n
         its = args.steps / dt
-        bytes_iter = ELEMS_ITER[reg] * 8.0 * kmn_total
+        bytes_iter = ELEMS_ITER[reg] * esz * kmn_total
         dual_ms, dual_n = times["dual"]
         dual_avg_s = dual_ms / max(dual_n, 1) * 1e-3
         # the dominant kernel processes this rank's slab; algorithmic bytes per launch = elements x 8 B x pixel-images
-        dual_bytes = ELEMS_DOM[reg] * 8.0 * float(k) * m * part.nl
+        dual_bytes = ELEMS_DOM[reg] * esz * float(k) * m * part.nl
         achieved = dual_bytes / dual_avg_s / 1e9 if dual_avg_s > 0 else 0.0
         out = {
-            "metric": "CP iterations/sec, NN-TV registration 4096^2 x K=16" if (reg == "tv" and m == 4096 and k == 16)
-            else f"CP iterations/sec, NN-{reg} registration {m}^2 x K={k}",
+            "metric": "CP iterations/sec, NN-TV registration 4096^2 x K=16" if (reg == "tv" and m == 4096 and k == 16 and not args.fp32)
+            else f"CP iterations/sec, NN-{reg} registration {m}^2 x K={k}" + (" (fp32 storage mode)" if args.fp32 else ""),
             "value": its,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -217,10 +219,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if not args.fp32 else "f64 arithmetic on f32 storage",
             "data": "synthetic",
             "config": {"workload": f"mf_nn_{reg}_registration_no_ref_ml inner CP iteration, finest level, "
-                                   f"{m}x{n}, K={k}, fp64, bc={bc}, theta=1, mu={mu}, nu from schedule, tau=sigma from "
+                                   f"{m}x{n}, K={k}, {'fp32 storage' if args.fp32 else 'fp64'}, bc={bc}, theta=1, mu={mu}, nu from schedule, tau=sigma from "
                                    f"power iteration ({n_power} its)",
                        "parallelism": f"row slabs x{world}" if world > 1 else "single GPU",
                        "achieved_GBps_algorithmic": bytes_iter * its / 1e9,

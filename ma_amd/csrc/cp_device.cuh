@@ -154,17 +154,23 @@ __device__ __forceinline__ void svt_2x2(double a, double c, double b, double d, 
 // Uniform base (SGPR pair) + 32-bit per-lane byte offset + immediate: the global_load/store "saddr" form. One VGPR per
 // distinct offset instead of a 64-bit VGPR address per access, and no per-access 64-bit VALU address arithmetic.
 // `ubase` must be wave-uniform; a field is < 4 GiB so the byte offset fits 32 bits.
-__device__ __forceinline__ double ldo(const double *__restrict__ ubase, unsigned off, int delta = 0) {
-    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(ubase) + (size_t)off + (ptrdiff_t)delta);
+// S = storage type of a field (double, or float in the fp32 mode); values are always returned / taken as double.
+template <typename S>
+__device__ __forceinline__ double rnd(double v) { return (double)(S)v; }   // what a store of v keeps
+template <typename S>
+__device__ __forceinline__ double ldo(const S *__restrict__ ubase, unsigned off, int delta = 0) {
+    return (double)*reinterpret_cast<const S *>(reinterpret_cast<const char *>(ubase) + (size_t)off + (ptrdiff_t)delta);
 }
-__device__ __forceinline__ void sto(double *__restrict__ ubase, unsigned off, double v) {
+template <typename S>
+__device__ __forceinline__ void sto(S *__restrict__ ubase, unsigned off, double v) {
     // streaming store: results are not read again by the launch that writes them, so they should not displace the
     // neighbour lines other workgroups are about to re-read from L2 (measured: -2 GB fetched, -1.5..3 % time)
-    __builtin_nontemporal_store(v, reinterpret_cast<double *>(reinterpret_cast<char *>(ubase) + (size_t)off));
+    __builtin_nontemporal_store((S)v, reinterpret_cast<S *>(reinterpret_cast<char *>(ubase) + (size_t)off));
 }
 // single-use streams (read by exactly one thread of the launch)
-__device__ __forceinline__ double ldo_stream(const double *__restrict__ ubase, unsigned off) {
-    return __builtin_nontemporal_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(ubase) + (size_t)off));
+template <typename S>
+__device__ __forceinline__ double ldo_stream(const S *__restrict__ ubase, unsigned off) {
+    return (double)__builtin_nontemporal_load(reinterpret_cast<const S *>(reinterpret_cast<const char *>(ubase) + (size_t)off));
 }
 
 // sqrt(x) and 1/sqrt(x) from one v_rsq_f64 and the Goldschmidt / residual steps of the compiler's own f64 sqrt

@@ -55,7 +55,7 @@ struct PassTimer {
 struct cp_engine {
     cp_problem_desc d;
     bool mf = false;     // multi-image model (mf_nn or var): K images, CpCtrl, MfParams
-    bool fp32 = false;   // CP_FLAG_FP32 (pairwise models): fields stored as float inside the double-sized allocations
+    bool fp32 = false;   // CP_FLAG_FP32 (pairwise, mf_nn): fields stored as float inside the double-sized allocations
     double *vwarm = nullptr;   // NN-TV: eigenvector bases of the previous iteration (2 x 256), warm start of k_mf_efused
     double *stage = nullptr;   // fp32 mode: one field of doubles for host <-> device conversion
     bool var = false;    // variance model (no L block, no nuclear norm): cp_var.cuh
@@ -259,7 +259,10 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         h->d.omega[3] = h->d.n_global * d.h[1];
     }
     if (pw && (h->d.n_global != d.n)) { delete h; CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported slabs for pairwise models"); }
-    if ((d.flags & CP_FLAG_FP32) && !pw) { delete h; CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported the fp32 mode covers the pairwise models"); }
+    if ((d.flags & CP_FLAG_FP32) && (var || (mf && h->d.n_global != d.n))) {
+        delete h;
+        CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported the fp32 mode covers the pairwise and mf_nn models on a full domain");
+    }
     h->fp32 = (d.flags & CP_FLAG_FP32) != 0;
     h->mf = mf;
     h->var = var;
@@ -327,6 +330,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             HIPCHK(hipMalloc(&h->part2, sizeof(double) * (size_t)(CP_FUSED_MAXGRID / CP_S1_GROUP) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->svout, sizeof(double) * (16 + 256 + 256)));
             HIPCHK(hipMalloc(&h->red, sizeof(double) * CP_PSTRIDE));
+            if (h->fp32) HIPCHK(hipMalloc(&h->stage, sizeof(double) * h->npix));
             HIPCHK(hipMalloc(&h->vwarm, sizeof(double) * 512));
             HIPCHK(hipMemsetAsync(h->vwarm, 0, sizeof(double) * 512, h->stream));
             HIPCHK(hipMalloc(&h->ctrl, sizeof(CpCtrl)));
@@ -427,7 +431,11 @@ extern "C" int cp_linearize(cp_handle h, const double *u0) {
         W.npix = h->m * (jhi - W.jlo + 1);
         const long long tot = (long long)W.npix * h->K;
         const int grid = (int)((tot + CP_BLOCK - 1) / CP_BLOCK);
-        hipLaunchKernelGGL(k_mf_warp, dim3(grid), dim3(CP_BLOCK), 0, h->stream, W, h->img, xsrc, h->Tu, h->g, h->b);
+        if (h->fp32)
+            hipLaunchKernelGGL((k_mf_warp<float>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, W, h->img, (const float *)xsrc,
+                               (float *)h->Tu, (float *)h->g, (float *)h->b);
+        else
+            hipLaunchKernelGGL((k_mf_warp<double>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, W, h->img, xsrc, h->Tu, h->g, h->b);
         if (h->var)   // b <- B*b, NNE/var_tv_registration_no_ref_ml.m:153-154
             hipLaunchKernelGGL(k_var_center_b, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, mf_params(h, 1.0, 1.0, 1.0), h->b);
     } else {
@@ -472,6 +480,39 @@ extern "C" int cp_set_nu(cp_handle h, double nu) {
 }
 
 // ------------------------------------------------------------------------------------------------
+static void launch_gram_field(cp_engine *h, const MfParams &P, const double *field, const double *Vm) {
+    if (h->fp32)
+        hipLaunchKernelGGL((k_mf_gram_field<float>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (const float *)field, Vm, h->part);
+    else
+        hipLaunchKernelGGL((k_mf_gram_field<double>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, field, Vm, h->part);
+}
+// y = A*(scale*x) and xo = A'*y of the power iteration; its vectors are doubles in every mode (the spare buffers
+// are double-sized), only the gradient field follows the storage mode
+static void launch_mf_applyA(cp_engine *h, const MfParams &P, const double *x, double scale, double *y) {
+    if (h->fp32) {
+        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyA<float, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
+        else hipLaunchKernelGGL((k_mf_applyA<float, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
+    } else {
+        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyA<double, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
+        else hipLaunchKernelGGL((k_mf_applyA<double, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
+    }
+}
+static void launch_mf_applyAT(cp_engine *h, const MfParams &P, const double *y, double *xo) {
+    if (h->fp32) {
+        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyAT<float, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
+        else hipLaunchKernelGGL((k_mf_applyAT<float, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
+    } else {
+        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyAT<double, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
+        else hipLaunchKernelGGL((k_mf_applyAT<double, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
+    }
+}
+// the power iteration's vectors move between host and device as doubles in every mode
+struct Fp64Transfers {
+    cp_engine *h; bool saved;
+    explicit Fp64Transfers(cp_engine *e) : h(e), saved(e->fp32) { h->fp32 = false; }
+    ~Fp64Transfers() { h->fp32 = saved; }
+};
+
 // singular values of reshape(B*field, mn, k): Gram -> Jacobi, then a second Gram in the rotated basis
 // (column norms are sums of squares, so small singular values keep their relative accuracy).
 extern "C" int cp_singular_values(cp_handle h, int which, double *sv) {
@@ -485,17 +526,17 @@ extern "C" int cp_singular_values(cp_handle h, int which, double *sv) {
         field = h->Tu;
     } else if (which == 1) {
         if (h->var) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported the variance models have no L block");
-        field = h->X[0] + (size_t)2 * h->K * h->fs;
+        field = h->fp32 ? (const double *)((const float *)h->X[0] + (size_t)2 * h->K * h->fs) : h->X[0] + (size_t)2 * h->K * h->fs;
     } else {
         CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg which = %d", which);
     }
     MfParams P = mf_params(h, 1.0, 1.0, 1.0);
     double *ident = h->svout + 16 + 256, *vout = h->svout + 16;
-    hipLaunchKernelGGL(k_mf_gram_field, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, field, ident, h->part);
+    launch_gram_field(h, P, field, ident);
     hipLaunchKernelGGL(k_mf_sv_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, h->nblk, h->part, ident, h->svout);
     // second pass in the rotated basis; W[2] (scratch) receives the rotation
     HIPCHK(hipMemcpyAsync(h->W[2], vout, sizeof(double) * 256, hipMemcpyDeviceToDevice, h->stream));
-    hipLaunchKernelGGL(k_mf_gram_field, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, field, h->W[2], h->part);
+    launch_gram_field(h, P, field, h->W[2]);
     hipLaunchKernelGGL(k_mf_sv_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, h->nblk, h->part, h->W[2], h->svout);
     HIPCHK(hipGetLastError());
     double lam[16];
@@ -519,7 +560,7 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
     double *xa = h->X[1], *xb = h->xtmp, *yb = h->P[1];   // spare buffers (state lives in X[0], P[0])
     HIPCHK(hipMemsetAsync(xa, 0, sizeof(double) * h->xN, h->stream));
     HIPCHK(hipMemsetAsync(xb, 0, sizeof(double) * h->xN, h->stream));
-    if (x0) CPCHK(upload_fields(h, xa, x0, h->nxf));
+    if (x0) { Fp64Transfers t(h); CPCHK(upload_fields(h, xa, x0, h->nxf)); }
     else hipLaunchKernelGGL(k_mf_hash_start, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->nxf, xa);
     // ||x0||
     std::vector<double> hp((size_t)h->nblk * CP_PSTRIDE);
@@ -535,6 +576,7 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
     {
         // reuse applyAT's reduction for ||x||^2 would need y; do it on the host once (start vector only)
         std::vector<double> hx((size_t)h->npix * h->nxf);
+        Fp64Transfers t(h);
         CPCHK(download_fields(h, xa, hx.data(), h->nxf));
         for (double v : hx) nrm2 += v * v;
     }
@@ -551,12 +593,9 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
         } else if (h->var) {
             hipLaunchKernelGGL((k_var_applyA<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa, scale, h->g, yb);
             hipLaunchKernelGGL((k_var_applyAT<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, yb, h->g, xb, h->part);
-        } else if (h->reg == 0) {
-            hipLaunchKernelGGL((k_mf_applyA<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa, scale, h->g, yb);
-            hipLaunchKernelGGL((k_mf_applyAT<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, yb, h->g, xb, h->part);
         } else {
-            hipLaunchKernelGGL((k_mf_applyA<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa, scale, h->g, yb);
-            hipLaunchKernelGGL((k_mf_applyAT<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, yb, h->g, xb, h->part);
+            launch_mf_applyA(h, P, xa, scale, yb);
+            launch_mf_applyAT(h, P, yb, xb);
         }
         HIPCHK(hipGetLastError());
         double ss;
@@ -579,21 +618,42 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
 template <int MODE>
 static void launch_mf_dual(cp_engine *h, const MfParams &P, const double *xc, const double *xo, const double *pin,
                            double *pout, const double *W, int cc, int co) {
+    if (h->fp32) {
+        const float *xcf = (const float *)xc, *xof = (const float *)xo, *pinf = (const float *)pin;
+        const float *gf = (const float *)h->g, *bf = (const float *)h->b;
+        if (h->reg == 0)
+            hipLaunchKernelGGL((k_mf_dual<float, MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xcf, xof, pinf,
+                               (float *)pout, gf, bf, W, (const CpCtrl *)h->ctrl, cc, co, h->part);
+        else
+            hipLaunchKernelGGL((k_mf_dual<float, MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xcf, xof, pinf,
+                               (float *)pout, gf, bf, W, (const CpCtrl *)h->ctrl, cc, co, h->part);
+        return;
+    }
     if (h->reg == 0)
-        hipLaunchKernelGGL((k_mf_dual<MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout, h->g,
+        hipLaunchKernelGGL((k_mf_dual<double, MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout, h->g,
                            h->b, W, (const CpCtrl *)h->ctrl, cc, co, h->part);
     else
-        hipLaunchKernelGGL((k_mf_dual<MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout, h->g,
+        hipLaunchKernelGGL((k_mf_dual<double, MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout, h->g,
                            h->b, W, (const CpCtrl *)h->ctrl, cc, co, h->part);
 }
 template <int MODE>
 static void launch_mf_primal(cp_engine *h, const MfParams &P, const double *xc, double *xn, const double *p,
                              const double *W, int cc) {
+    if (h->fp32) {
+        const float *xcf = (const float *)xc, *pf = (const float *)p, *gf = (const float *)h->g;
+        if (h->reg == 0)
+            hipLaunchKernelGGL((k_mf_primal<float, MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xcf, (float *)xn, pf,
+                               gf, W, (const CpCtrl *)h->ctrl, cc, h->part);
+        else
+            hipLaunchKernelGGL((k_mf_primal<float, MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xcf, (float *)xn, pf,
+                               gf, W, (const CpCtrl *)h->ctrl, cc, h->part);
+        return;
+    }
     if (h->reg == 0)
-        hipLaunchKernelGGL((k_mf_primal<MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g, W,
+        hipLaunchKernelGGL((k_mf_primal<double, MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g, W,
                            (const CpCtrl *)h->ctrl, cc, h->part);
     else
-        hipLaunchKernelGGL((k_mf_primal<MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g, W,
+        hipLaunchKernelGGL((k_mf_primal<double, MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g, W,
                            (const CpCtrl *)h->ctrl, cc, h->part);
 }
 
@@ -632,15 +692,22 @@ static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int
     return CP_OK;
 }
 
-typedef void (*fused_kernel_t)(MfParams, const double *, double *, const double *, double *, const double *, const double *,
-                               const double *, const CpCtrl *, double *);
-template <int TW>
-static fused_kernel_t fused_kernel_tw(const cp_engine *h) {
-    return (h->d.bc == CP_BC_LINEAR) ? (h->K == CP_KMAX ? k_mf_fused_tv<true, true, TW> : k_mf_fused_tv<true, false, TW>)
-                                     : (h->K == CP_KMAX ? k_mf_fused_tv<false, true, TW> : k_mf_fused_tv<false, false, TW>);
+// one launch of k_mf_fused_tv: x_{n-1} in xp, x_n written to xc; y_n in pc, y_{n+1} written to pn
+template <typename S, int TW>
+static void launch_fused_tw(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
+                            const double *W) {
+    auto kern = (h->d.bc == CP_BC_LINEAR)
+                    ? (h->K == CP_KMAX ? k_mf_fused_tv<S, true, true, TW> : k_mf_fused_tv<S, true, false, TW>)
+                    : (h->K == CP_KMAX ? k_mf_fused_tv<S, false, true, TW> : k_mf_fused_tv<S, false, false, TW>);
+    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
+                       (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
 }
-static fused_kernel_t fused_kernel(const cp_engine *h) {
-    return h->fused_tw == 1 ? fused_kernel_tw<1>(h) : (h->fused_tw == 2 ? fused_kernel_tw<2>(h) : fused_kernel_tw<4>(h));
+static void launch_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
+                         const double *W) {
+    if (h->fp32) launch_fused_tw<float, 1>(h, P, xp, xc, pc, pn, W);   // the tile-width knob is an fp64 tuning aid
+    else if (h->fused_tw == 1) launch_fused_tw<double, 1>(h, P, xp, xc, pc, pn, W);
+    else if (h->fused_tw == 2) launch_fused_tw<double, 2>(h, P, xp, xc, pc, pn, W);
+    else launch_fused_tw<double, 4>(h, P, xp, xc, pc, pn, W);
 }
 
 // First stage of the reduction of the fused kernel's partial rows: output row r = fixed-order sum (slots < CP_NSUM and
@@ -698,11 +765,7 @@ static int mf_fused_iterations(cp_engine *h, const MfParams &P, int n0, int coun
     for (int n = n0 + 1; n <= n0 + count; ++n) {
         const int cur = n & 1, prv = (n - 1) & 1, nxt = (n + 1) & 1;   // x_{n-1} in X[prv], y_n in P[cur]
         CPCHK(timer_begin(h, T_DUAL));
-        {
-            auto kern = fused_kernel(h);
-            hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, h->X[prv], h->X[cur], h->P[cur],
-                               h->P[nxt], h->g, h->b, h->W[cur], (const CpCtrl *)ctrl, h->part);
-        }
+        launch_fused(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[nxt], h->W[cur]);
         CPCHK(timer_end(h, T_DUAL));
         EFusedArgs A;
         A.K = h->K; A.n = n; A.check_stop = check; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
@@ -727,11 +790,20 @@ static int mf_begin(cp_engine *h) {
 
 static int mf_end(cp_engine *h, const MfParams &P, int iterations) {
     const int fb = iterations & 1;
-    if (h->reg == 0)
-        hipLaunchKernelGGL((k_mf_materialize<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[fb], h->X[0],
+    if (h->fp32) {
+        const float *xs = (const float *)h->X[fb], *ps = (const float *)h->P[fb];
+        float *xd = (float *)h->X[0], *pd = (float *)h->P[0];
+        if (h->reg == 0)
+            hipLaunchKernelGGL((k_mf_materialize<float, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xs, xd, ps, pd,
+                               h->W[fb], (const CpCtrl *)h->ctrl, fb);
+        else
+            hipLaunchKernelGGL((k_mf_materialize<float, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xs, xd, ps, pd,
+                               h->W[fb], (const CpCtrl *)h->ctrl, fb);
+    } else if (h->reg == 0)
+        hipLaunchKernelGGL((k_mf_materialize<double, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[fb], h->X[0],
                            h->P[fb], h->P[0], h->W[fb], (const CpCtrl *)h->ctrl, fb);
     else
-        hipLaunchKernelGGL((k_mf_materialize<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[fb], h->X[0],
+        hipLaunchKernelGGL((k_mf_materialize<double, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[fb], h->X[0],
                            h->P[fb], h->P[0], h->W[fb], (const CpCtrl *)h->ctrl, fb);
     hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1]);
     HIPCHK(hipGetLastError());
@@ -1055,14 +1127,15 @@ extern "C" int cp_get_history(cp_handle h, double *primal_history, double *dual_
 }
 
 // ------------------------------------------------------------------------------------------------
+template <typename S>
 __global__ void k_prolong(int m, int n, int fs, int ml, int nlw, int fsl, int nfields, double factor,
-                          const double *__restrict__ xl, double *__restrict__ xh) {
+                          const S *__restrict__ xl, S *__restrict__ xh) {
     const long long tot = (long long)m * n * nfields;
     for (long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot; gid += (long long)gridDim.x * CP_BLOCK) {
         const int f = (int)(gid / ((long long)m * n)), q = (int)(gid - (long long)f * m * n);
         const int j = q / m, i = q - j * m;
         // kron(x_low, ones(2)) cropped to (1:m, 1:n)          NNE/mf_nn_tv...:113-119
-        xh[(size_t)f * fs + m + q] = factor * xl[(size_t)f * fsl + ml + (size_t)(j >> 1) * ml + (i >> 1)];
+        xh[(size_t)f * fs + m + q] = (S)(factor * (double)xl[(size_t)f * fsl + ml + (size_t)(j >> 1) * ml + (i >> 1)]);
     }
 }
 
@@ -1075,11 +1148,15 @@ extern "C" int cp_prolong(cp_handle coarse, cp_handle fine, double factor) {
     HIPCHK(hipSetDevice(fine->d.device));
     CP_NOT_ITERATING(coarse);
     CP_NOT_ITERATING(fine);
-    if (coarse->fp32 || fine->fp32) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_prolong in fp32 mode");
+    if (coarse->fp32 != fine->fp32) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg handles differ in storage mode");
     HIPCHK(hipStreamSynchronize(coarse->stream));
     const int nf = fine->nxf * fine->batch;
-    hipLaunchKernelGGL(k_prolong, dim3(2048), dim3(CP_BLOCK), 0, fine->stream, fine->m, fine->nl, fine->fs, coarse->m,
-                       coarse->nl, coarse->fs, nf, factor, coarse->X[0], fine->X[0]);
+    if (fine->fp32)
+        hipLaunchKernelGGL((k_prolong<float>), dim3(2048), dim3(CP_BLOCK), 0, fine->stream, fine->m, fine->nl, fine->fs, coarse->m,
+                           coarse->nl, coarse->fs, nf, factor, (const float *)coarse->X[0], (float *)fine->X[0]);
+    else
+        hipLaunchKernelGGL((k_prolong<double>), dim3(2048), dim3(CP_BLOCK), 0, fine->stream, fine->m, fine->nl, fine->fs, coarse->m,
+                           coarse->nl, coarse->fs, nf, factor, coarse->X[0], fine->X[0]);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(fine->P[0], 0, sizeof(double) * fine->pN, fine->stream));   // p = zeros (:122)
     HIPCHK(hipStreamSynchronize(fine->stream));
@@ -1318,6 +1395,7 @@ extern "C" int64_t cp_mg_halo_len(cp_handle h, int sel) {
 }
 static int mg_halo(cp_handle h, int buf, int sel, int col, int pack, double *lin) {
     if (!h || !h->mf || !lin) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg halo exchange needs an mf_nn handle and a buffer");
+    if (h->fp32) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported halo exchange in fp32 mode");
     HIPCHK(hipSetDevice(h->d.device));
     double *b = mg_buf(h, buf);
     const int nsel = mg_nsel(h, buf, sel);
@@ -1373,9 +1451,7 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             if (n + 2 > h->hist_rows) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg iteration %d beyond the history capacity", n);
             const int cur = n & 1, prv = (n - 1) & 1, nxt = (n + 1) & 1;
             CPCHK(timer_begin(h, T_DUAL));
-            auto kern = fused_kernel(h);
-            hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, h->X[prv], h->X[cur], h->P[cur],
-                               h->P[nxt], h->g, h->b, h->W[cur], (const CpCtrl *)ctrl, h->part);
+            launch_fused(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[nxt], h->W[cur]);
             CPCHK(timer_end(h, T_DUAL));
             int nrows = 0;
             const double *rows = fused_partials(h, &nrows);
@@ -1424,16 +1500,10 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             break;
         }
         case CP_STAGE_APPLY_A:
-            if (h->reg == 0)
-                hipLaunchKernelGGL((k_mf_applyA<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[1], scale, h->g, h->P[1]);
-            else
-                hipLaunchKernelGGL((k_mf_applyA<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[1], scale, h->g, h->P[1]);
+            launch_mf_applyA(h, P, h->X[1], scale, h->P[1]);
             break;
         case CP_STAGE_APPLY_AT:
-            if (h->reg == 0)
-                hipLaunchKernelGGL((k_mf_applyAT<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->P[1], h->g, h->xtmp, h->part);
-            else
-                hipLaunchKernelGGL((k_mf_applyAT<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->P[1], h->g, h->xtmp, h->part);
+            launch_mf_applyAT(h, P, h->P[1], h->xtmp);
             hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk, h->part, dev_buf);
             std::swap(h->X[1], h->xtmp);
             break;
@@ -1475,7 +1545,9 @@ extern "C" int cp_mg_gram(cp_handle h, int which, const double *V, double *gram)
     if (!h || !h->mf || h->var || !gram) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_gram");
     HIPCHK(hipSetDevice(h->d.device));
     CP_NOT_ITERATING(h);
-    const double *field = (which == 0) ? h->Tu : h->X[0] + (size_t)2 * h->K * h->fs;
+    const double *field = (which == 0) ? h->Tu
+                          : (h->fp32 ? (const double *)((const float *)h->X[0] + (size_t)2 * h->K * h->fs)
+                                     : h->X[0] + (size_t)2 * h->K * h->fs);
     if (which == 0 && !h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_gram(0) before cp_linearize");
     MfParams P = mf_params(h, 1.0, 1.0, 1.0);
     double *ident = h->svout + 16 + 256, *Vd = ident;
@@ -1483,7 +1555,7 @@ extern "C" int cp_mg_gram(cp_handle h, int which, const double *V, double *gram)
         HIPCHK(hipMemcpyAsync(h->W[2], V, sizeof(double) * 256, hipMemcpyHostToDevice, h->stream));
         Vd = h->W[2];
     }
-    hipLaunchKernelGGL(k_mf_gram_field, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, field, Vd, h->part);
+    launch_gram_field(h, P, field, Vd);
     // only the first Gram block of the partials is written by k_mf_gram_field: clear the rest first
     HIPCHK(hipGetLastError());
     std::vector<double> hp((size_t)h->nblk * CP_PSTRIDE);

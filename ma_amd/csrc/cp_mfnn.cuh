@@ -52,7 +52,8 @@ enum { DM_Y1 = CP_NSUM, DM_S1,                                            // dua
 
 // y3 = y3~ * W for the wave's pixel: loads the K stored values, multiplies by the K x K matrix W (staged in LDS,
 // broadcast reads) and leaves the result in tile[k][lane]; returns sum_k y3[k].
-__device__ __forceinline__ double load_y3_apply_W(const double *__restrict__ y3base, int fs, int e, bool valid,
+template <typename S>
+__device__ __forceinline__ double load_y3_apply_W(const S *__restrict__ y3base, int fs, int e, bool valid,
                                                   int K, const double *Wl, double *tile, int lane) {
     double a[CP_KMAX];
 #pragma unroll
@@ -81,11 +82,11 @@ __device__ __forceinline__ void stage_W(const double *__restrict__ W, double *Wl
 
 // MODE 0: update (writes pout); MODE 1: monitor only (y_new := y_in, nothing written but the partials).
 // REG 0: TV (forward differences + pointwise 2x2 nuclear norm); REG 1: curvature (Laplacian + SSD).
-template <int MODE, int REG>
-__global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *__restrict__ xc,
-                                                      const double *__restrict__ xo,
-                                                      const double *__restrict__ pin, double *__restrict__ pout,
-                                                      const double *__restrict__ g, const double *__restrict__ b,
+template <typename S, int MODE, int REG>
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const S *__restrict__ xc,
+                                                      const S *__restrict__ xo,
+                                                      const S *__restrict__ pin, S *__restrict__ pout,
+                                                      const S *__restrict__ g, const S *__restrict__ b,
                                                       const double *__restrict__ W, const CpCtrl *__restrict__ ctrl,
                                                       int cbuf_c, int cbuf_o, double *__restrict__ part) {
     __shared__ double tiles[CP_WAVES * 16 * CP_TS];
@@ -102,8 +103,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
     const double cox = ctrl->c[cbuf_o][0], coy = ctrl->c[cbuf_o][1];
     const double sigma = P.sigma, theta = P.theta, inv_sigma = 1.0 / P.sigma;
     const int NY2 = (REG == 0) ? 4 : 2;
-    const double *y3in = pin + (size_t)(K + NY2 * K) * fs;
-    double *y3out = pout + (size_t)(K + NY2 * K) * fs;
+    const S *y3in = pin + (size_t)(K + NY2 * K) * fs;
+    S *y3out = pout + (size_t)(K + NY2 * K) * fs;
 
     double sums[CP_NSUM], maxs[CP_NMAX];
 #pragma unroll
@@ -127,8 +128,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
         double sumLbar = 0.0;
         for (int k = 0; k < K; ++k) {
             if (valid) {
-                const double *uxc = xc + (size_t)(2 * k) * fs + e, *uyc = xc + (size_t)(2 * k + 1) * fs + e;
-                const double *uxo = xo + (size_t)(2 * k) * fs + e, *uyo = xo + (size_t)(2 * k + 1) * fs + e;
+                const S *uxc = xc + (size_t)(2 * k) * fs + e, *uyc = xc + (size_t)(2 * k + 1) * fs + e;
+                const S *uxo = xo + (size_t)(2 * k) * fs + e, *uyo = xo + (size_t)(2 * k + 1) * fs + e;
                 const double Lc = xc[(size_t)(2 * K + k) * fs + e], Lo = xo[(size_t)(2 * K + k) * fs + e];
                 const double Lbar = Lc + theta * (Lc - Lo);
                 // true displacement values (stored - pending mean offset) and the over-relaxed point
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
                     // NNE/SAD.m:71-72 with the inner call :42-49 (sigma -> 1/sigma)
                     const double Ls = yt * inv_sigma, thr = inv_sigma * P.mu1, dd = Ls - bb;
                     const double prox = (dd > thr) ? (Ls - thr) : ((dd < -thr) ? (Ls + thr) : bb);
-                    y1n = yt - sigma * prox;
-                    pout[(size_t)k * fs + e] = y1n;
+                    y1n = rnd<S>(yt - sigma * prox);
+                    pout[(size_t)k * fs + e] = (S)y1n;
                 } else {
                     y1n = y1;
                 }
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
                     double s1v, s2v;
                     sv_2x2(d0, d1, d2, d3, s1v, s2v);
                     sums[DS_F2] += s1v + s2v;                          // NNE/pointwise_2x2_nn.m:32
-                    const double *y2 = pin + (size_t)(K + 4 * k) * fs + e;
+                    const S *y2 = pin + (size_t)(K + 4 * k) * fs + e;
                     const double v0 = y2[0], v1 = y2[(size_t)fs], v2 = y2[2 * (size_t)fs], v3 = y2[3 * (size_t)fs];
                     double n0, n1, n2, n3;
                     if (MODE == 0) {
@@ -201,9 +202,10 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
                         double r0, r1, r2, r3;
                         svt_2x2(t0 * inv_sigma, t1 * inv_sigma, t2 * inv_sigma, t3 * inv_sigma, P.mu2 * inv_sigma, r0,
                                 r1, r2, r3);
-                        n0 = t0 - sigma * r0; n1 = t1 - sigma * r1; n2 = t2 - sigma * r2; n3 = t3 - sigma * r3;
-                        double *o2 = pout + (size_t)(K + 4 * k) * fs + e;
-                        o2[0] = n0; o2[(size_t)fs] = n1; o2[2 * (size_t)fs] = n2; o2[3 * (size_t)fs] = n3;
+                        n0 = rnd<S>(t0 - sigma * r0); n1 = rnd<S>(t1 - sigma * r1);
+                        n2 = rnd<S>(t2 - sigma * r2); n3 = rnd<S>(t3 - sigma * r3);
+                        S *o2 = pout + (size_t)(K + 4 * k) * fs + e;
+                        o2[0] = (S)n0; o2[(size_t)fs] = (S)n1; o2[2 * (size_t)fs] = (S)n2; o2[3 * (size_t)fs] = (S)n3;
                     } else {
                         n0 = v0; n1 = v1; n2 = v2; n3 = v3;
                     }
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
                     double lapc[2], lapb[2];
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        const double *pc = c ? uyc : uxc, *po = c ? uyo : uxo;
+                        const S *pc = c ? uyc : uxc, *po = c ? uyo : uxo;
                         const double oc = c ? ccy : ccx, oo = c ? coy : cox;
                         const double uc0 = c ? uy : ux, ub0 = c ? uyb : uxb;
                         double nb[4], nbb[4];   // i-1, i+1, j-1, j+1
@@ -233,17 +235,17 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
                         lapb[c] = (nbb[0] + nbb[1] - 2.0 * ub0) * ih1 + (nbb[2] + nbb[3] - 2.0 * ub0) * ih2;
                     }
                     sums[DS_F2] += lapc[0] * lapc[0] + lapc[1] * lapc[1];        // NNE/SSD.m:48 (g = 0)
-                    const double *y2 = pin + (size_t)(K + 2 * k) * fs + e;
+                    const S *y2 = pin + (size_t)(K + 2 * k) * fs + e;
                     const double v0 = y2[0], v1 = y2[(size_t)fs];
                     double n0, n1;
                     if (MODE == 0) {
                         const double t0 = v0 + sigma * lapb[0], t1 = v1 + sigma * lapb[1];
                         // NNE/SSD.m:60-61 with :43 (g = 0): x - tau * ((x/tau) / (1 + lambda/tau))
                         const double den = 1.0 + P.mu2 * inv_sigma;
-                        n0 = t0 - sigma * ((t0 * inv_sigma) / den);
-                        n1 = t1 - sigma * ((t1 * inv_sigma) / den);
-                        double *o2 = pout + (size_t)(K + 2 * k) * fs + e;
-                        o2[0] = n0; o2[(size_t)fs] = n1;
+                        n0 = rnd<S>(t0 - sigma * ((t0 * inv_sigma) / den));
+                        n1 = rnd<S>(t1 - sigma * ((t1 * inv_sigma) / den));
+                        S *o2 = pout + (size_t)(K + 2 * k) * fs + e;
+                        o2[0] = (S)n0; o2[(size_t)fs] = (S)n1;
                     } else {
                         n0 = v0; n1 = v1;
                     }
@@ -261,10 +263,10 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
         if (MODE == 0) {
             const double sm = sigma * (sumLbar * P.invK);
             for (int k = 0; k < K; ++k) {
-                const double v = tile[k * CP_TS + lane] - sm;
+                const double v = rnd<S>(tile[k * CP_TS + lane] - sm);
                 if (valid) {
                     tile[k * CP_TS + lane] = v;
-                    y3out[(size_t)k * fs + e] = v;
+                    y3out[(size_t)k * fs + e] = (S)v;
                 }
             }
         }
@@ -277,10 +279,10 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const double *
     gram_block_store(acc, tiles, out + CP_NSCAL);
 }
 
-template <int MODE, int REG>
-__global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const double *__restrict__ xc,
-                                                        double *__restrict__ xn, const double *__restrict__ p,
-                                                        const double *__restrict__ g, const double *__restrict__ W,
+template <typename S, int MODE, int REG>
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const S *__restrict__ xc,
+                                                        S *__restrict__ xn, const S *__restrict__ p,
+                                                        const S *__restrict__ g, const double *__restrict__ W,
                                                         const CpCtrl *__restrict__ ctrl, int cbuf_c,
                                                         double *__restrict__ part) {
     __shared__ double tiles[CP_WAVES * 16 * CP_TS];
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const double
     const double ccx = ctrl->c[cbuf_c][0], ccy = ctrl->c[cbuf_c][1];
     const double tau = P.tau;
     const int NY2 = (REG == 0) ? 4 : 2;
-    const double *y3 = p + (size_t)(K + NY2 * K) * fs;
+    const S *y3 = p + (size_t)(K + NY2 * K) * fs;
 
     double sums[CP_NSUM], maxs[CP_NMAX];
 #pragma unroll
@@ -324,8 +326,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const double
                 const double Lc = xc[(size_t)(2 * K + k) * fs + e];
                 double Ln;
                 if (MODE == 0) {
-                    Ln = Lc - tau * vL;                                // zero_function prox = identity
-                    xn[(size_t)(2 * K + k) * fs + e] = Ln;
+                    Ln = rnd<S>(Lc - tau * vL);                        // zero_function prox = identity
+                    xn[(size_t)(2 * K + k) * fs + e] = (S)Ln;
                 } else {
                     Ln = Lc;
                 }
@@ -336,11 +338,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const double
                 const double gx = g[(size_t)(2 * k) * fs + e], gy = g[(size_t)(2 * k + 1) * fs + e];
                 double vux, vuy;
                 if (REG == 0) {
-                    const double *y2 = p + (size_t)(K + 4 * k) * fs + e;
+                    const S *y2 = p + (size_t)(K + 4 * k) * fs + e;
                     double adj[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const double *f = y2 + (size_t)c * fs;
+                        const S *f = y2 + (size_t)c * fs;
                         const double wc = f[0];
                         if ((c & 1) == 0) {   // Dx component: adjoint along i
                             const double wm = (i >= 1) ? f[-1] : 0.0;
@@ -356,11 +358,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const double
                     vuy = -gy * y1 + (adj[2] + adj[3]);
                 } else {
                     const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
-                    const double *y2 = p + (size_t)(K + 2 * k) * fs + e;
+                    const S *y2 = p + (size_t)(K + 2 * k) * fs + e;
                     double lap[2];
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        const double *f = y2 + (size_t)c * fs;
+                        const S *f = y2 + (size_t)c * fs;
                         const double w0 = f[0];
                         const double a0 = (i > 0) ? f[-1] : (neumann ? w0 : 0.0);
                         const double a1 = (i < m - 1) ? f[1] : (neumann ? w0 : 0.0);
@@ -373,9 +375,9 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const double
                 }
                 const double ux = xc[(size_t)(2 * k) * fs + e] - ccx, uy = xc[(size_t)(2 * k + 1) * fs + e] - ccy;
                 if (MODE == 0) {
-                    const double ntx = ux - tau * vux, nty = uy - tau * vuy;    // mean subtracted lazily (c of xn)
-                    xn[(size_t)(2 * k) * fs + e] = ntx;
-                    xn[(size_t)(2 * k + 1) * fs + e] = nty;
+                    const double ntx = rnd<S>(ux - tau * vux), nty = rnd<S>(uy - tau * vuy);    // mean subtracted lazily (c of xn)
+                    xn[(size_t)(2 * k) * fs + e] = (S)ntx;
+                    xn[(size_t)(2 * k + 1) * fs + e] = (S)nty;
                     sums[PS_UX] += ntx;
                     sums[PS_UY] += nty;
                 }

@@ -30,10 +30,10 @@ struct PixOff {
 // All loads are unconditional (every field has a halo column on both sides, so the +-1 element and +-1 column
 // neighbours are always inside the allocation); boundary handling happens in the arithmetic. This keeps the whole
 // per-image body one basic block, so the compiler can issue every load of the three positions before the first wait.
-template <bool LINEAR>
+template <typename S, bool LINEAR>
 __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, PixOff o, unsigned fsb,
-                                            const double *__restrict__ y1k, const double *__restrict__ y2k,
-                                            const double *__restrict__ gxk, const double *__restrict__ uxk,
+                                            const S *__restrict__ y1k, const S *__restrict__ y2k,
+                                            const S *__restrict__ gxk, const S *__restrict__ uxk,
                                             double cnx, double cny,
                                             double &uxn, double &uyn, double &uxo, double &uyo, double &wx, double &wy) {
     const int m = P.m;
@@ -42,12 +42,12 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
     double adj[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const double *f = y2k + (size_t)c * P.fs;
+        const S *f = y2k + (size_t)c * P.fs;
         const double wc = ldo(f, o.c);
         if ((c & 1) == 0) {   // Dx component: adjoint along i
-            const double wraw = ldo(f, o.c, -8);
+            const double wraw = ldo(f, o.c, -(int)sizeof(S));
             const double wm = (i >= 1) ? wraw : 0.0;
-            const double wl = LINEAR ? ldo(f, o.c + 8u * (unsigned)((m - 1) - i)) : 0.0;
+            const double wl = LINEAR ? ldo(f, o.c + (unsigned)sizeof(S) * (unsigned)((m - 1) - i)) : 0.0;
             adj[c] = fwd_diff_adj(wc, wm, wl, i, m, LINEAR, P.inv_h1);
         } else {              // Dy component: adjoint along j
             const double wraw = ldo(f, o.cm);
@@ -55,7 +55,7 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
             double wl = 0.0;
             if (LINEAR) {
                 const int dj = (jg >= P.n_global - 2) ? (P.n_global - 1) - jg : 0;
-                wl = ldo(f, o.c + 8u * (unsigned)(dj * m));
+                wl = ldo(f, o.c + (unsigned)sizeof(S) * (unsigned)(dj * m));
             }
             adj[c] = fwd_diff_adj(wc, wm, wl, jg, P.n_global, LINEAR, P.inv_h2);
         }
@@ -64,8 +64,8 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
     const double vuy = -gy * y1 + (adj[2] + adj[3]);
     uxo = ldo(uxk, o.c);
     uyo = ldo(uxk + P.fs, o.c);
-    uxn = (uxo - P.tau * vux) - cnx;          // NNE/mean_zero_indicator.m:50
-    uyn = (uyo - P.tau * vuy) - cny;          // :53
+    uxn = rnd<S>((uxo - P.tau * vux) - cnx);  // NNE/mean_zero_indicator.m:50 (the stored value is the iterate)
+    uyn = rnd<S>((uyo - P.tau * vuy) - cny);  // :53
     wx = -vux;
     wy = -vuy;
 }
@@ -75,11 +75,11 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
 // spill-over line of every wave a miss in the XCD's L2; TW = 1 measured best (see cp_create).
 __host__ __device__ inline int fused_tiles(int m, int nl, int tw) { return ((m + CP_BLOCK / tw - 1) / (CP_BLOCK / tw)) * ((nl + tw - 1) / tw); }
 
-template <bool LINEAR, bool FULLK, int TW>
-__global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const double *__restrict__ xo,
-                                                             double *__restrict__ xn, const double *__restrict__ pin,
-                                                             double *__restrict__ pout, const double *__restrict__ g,
-                                                             const double *__restrict__ b, const double *__restrict__ W,
+template <typename S, bool LINEAR, bool FULLK, int TW>
+__global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S *__restrict__ xo,
+                                                             S *__restrict__ xn, const S *__restrict__ pin,
+                                                             S *__restrict__ pout, const S *__restrict__ g,
+                                                             const S *__restrict__ b, const double *__restrict__ W,
                                                              const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
     __shared__ double tiles[CP_WAVES * 2 * 16 * CP_TS];
     __shared__ double red[CP_WAVES * CP_NSCAL];
@@ -94,11 +94,12 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
     __syncthreads();
     const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
     const double sigma = P.sigma, tau = P.tau, theta = P.theta, inv_sigma = 1.0 / P.sigma;
-    const double *y3in = pin + 5 * (size_t)K * fs;
-    double *y3out = pout + 5 * (size_t)K * fs;
-    const double *Lin = xo + 2 * (size_t)K * fs;
-    double *Lout = xn + 2 * (size_t)K * fs;
-    const unsigned mb = 8u * (unsigned)m, fsb = 8u * (unsigned)P.fs;
+    const S *y3in = pin + 5 * (size_t)K * fs;
+    S *y3out = pout + 5 * (size_t)K * fs;
+    const S *Lin = xo + 2 * (size_t)K * fs;
+    S *Lout = xn + 2 * (size_t)K * fs;
+    constexpr unsigned ES = (unsigned)sizeof(S);
+    const unsigned mb = ES * (unsigned)m, fsb = ES * (unsigned)P.fs;
 
     double sums[CP_NSUM], maxs[CP_NMAX];
 #pragma unroll
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
         const int ii = ti * TH + (tid % TH), jj = tj * TW + (tid / TH);
         const bool valid = (ii < m) && (jj < P.nl);
         const int i = min(ii, m - 1), j = min(jj, P.nl - 1);   // lanes past the end redo an edge pixel, nothing is stored
-        const unsigned off = 8u * (unsigned)((j + 1) * m + i);   // byte offset of (i, j) inside a field (halo column first)
+        const unsigned off = ES * (unsigned)((j + 1) * m + i);   // byte offset of (i, j) inside a field (halo column first)
         const int jg = P.j_off + j;
         const bool last_i = (i == m - 1), last_j = (jg == P.n_global - 1);
 
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
             const bool act = FULLK || (k < K);
             const double Lo = Lr[k];
             const double vL = y1v[k] + (a[k] - mean3);               // (A'y)_L = y1 + B*y3
-            const double Ln = Lo - tau * vL;                          // zero_function prox = identity
+            const double Ln = rnd<S>(Lo - tau * vL);                  // zero_function prox = identity
             const double Lb = Ln + theta * (Ln - Lo);                 // chambolle_pock.m:179
             vLmax = fmax(vLmax, act ? fabs(vL) : 0.0);                // NNE/zero_function.m:32
             Lr[k] = act ? Ln : 0.0;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
 #pragma unroll
         for (int k = 0; k < CP_KMAX; ++k) {
             const bool act = FULLK || (k < K);
-            const double v = (valid && act) ? a[k] - smb : 0.0;       // y3~_{n+1} = y3_n + sigma*B*Lbar
+            const double v = (valid && act) ? rnd<S>(a[k] - smb) : 0.0;   // y3~_{n+1} = y3_n + sigma*B*Lbar
             tileA[k * CP_TS + lane] = v;
             if (valid && act) {
                 sto(y3out + (size_t)k * fs, off, v);
@@ -187,22 +188,22 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
         // neighbours along i and j ("previous" instead of "next" on a linear boundary row; unused otherwise)
         const int oi = (last_i && LINEAR) ? -1 : 1, oj = (last_j && LINEAR) ? -1 : 1;
         const PixOff p0 = {off, off - mb};
-        const PixOff pi = {oi > 0 ? off + 8u : off - 8u, (oi > 0 ? off + 8u : off - 8u) - mb};
+        const PixOff pi = {oi > 0 ? off + ES : off - ES, (oi > 0 ? off + ES : off - ES) - mb};
         const PixOff pj = {oj > 0 ? off + mb : off - mb, oj > 0 ? off : off - 2u * mb};
         const double vmask = valid ? 1.0 : 0.0;
         for (int k = 0; k < K; ++k) {
-            const double *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
-            const double *gxk = g + 2 * (size_t)k * fs, *uxk = xo + 2 * (size_t)k * fs;
+            const S *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
+            const S *gxk = g + 2 * (size_t)k * fs, *uxk = xo + 2 * (size_t)k * fs;
             const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
             double ux, uy, uxo_, uyo_, wx, wy, uxi, uyi, oi0, oi1, uxj, uyj, oj0, oj1, wd0, wd1;
-            primal_u_at<LINEAR>(P, i, jg, p0, fsb, y1k, y2k, gxk, uxk, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
-            primal_u_at<LINEAR>(P, i + oi, jg, pi, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
-            primal_u_at<LINEAR>(P, i, jg + oj, pj, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
+            primal_u_at<S, LINEAR>(P, i, jg, p0, fsb, y1k, y2k, gxk, uxk, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
+            primal_u_at<S, LINEAR>(P, i + oi, jg, pi, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
+            primal_u_at<S, LINEAR>(P, i, jg + oj, pj, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
             const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
             const double bb = ldo_stream(b + (size_t)k * fs, off);
             const double y1 = ldo(y1k, off);
             const double v0 = ldo(y2k, off), v1 = ldo(y2k + fs, off), v2 = ldo(y2k + 2 * fs, off), v3 = ldo(y2k + 3 * fs, off);
-            double *uxo_k = xn + 2 * (size_t)k * fs;
+            S *uxo_k = xn + 2 * (size_t)k * fs;
 
             if (valid) {
                 sto(uxo_k, off, ux);
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
             const double yt = y1 + sigma * r_bar;
             const double Ls = yt * inv_sigma, thr = inv_sigma * P.mu1, dd = Ls - bb;
             const double prox = (dd > thr) ? (Ls - thr) : ((dd < -thr) ? (Ls + thr) : bb);   // :42-49
-            const double y1n = yt - sigma * prox;                              // :71-72
+            const double y1n = rnd<S>(yt - sigma * prox);                      // :71-72
             sums[DS_F1S] += vmask * (y1n * bb);                                // :83
             sums[DS_SGX] += vmask * (gx * y1n);
             sums[DS_SGY] += vmask * (gy * y1n);
@@ -243,8 +244,9 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const d
             const double t0 = v0 + sigma * e0, t1 = v1 + sigma * e1, t2 = v2 + sigma * e2, t3 = v3 + sigma * e3;
             double n0, n1, n2, n3, s1v;
             proj_spectral_2x2(t0, t1, t2, t3, P.mu2, n0, n1, n2, n3, s1v);     // :46-48 (Moreau), :56
+            if (sizeof(S) == 4) { n0 = rnd<S>(n0); n1 = rnd<S>(n1); n2 = rnd<S>(n2); n3 = rnd<S>(n3); }
             if (valid) {
-                double *o1 = pout + (size_t)k * fs, *o2 = pout + ((size_t)K + 4 * (size_t)k) * fs;
+                S *o1 = pout + (size_t)k * fs, *o2 = pout + ((size_t)K + 4 * (size_t)k) * fs;
                 sto(o1, off, y1n);
                 sto(o2, off, n0); sto(o2 + fs, off, n1); sto(o2 + 2 * fs, off, n2); sto(o2 + 3 * fs, off, n3);
                 maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], fabs(y1n));

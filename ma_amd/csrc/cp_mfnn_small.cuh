@@ -353,10 +353,10 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_fin(EigArgs A, const doub
 }
 
 // ---- state canonicalisation: apply pending offsets / W so that the stored vectors are the true ones ---
-template <int REG>
-__global__ __launch_bounds__(CP_BLOCK) void k_mf_materialize(MfParams P, const double *__restrict__ xs,
-                                                             double *__restrict__ xd, const double *__restrict__ ps,
-                                                             double *__restrict__ pd, const double *__restrict__ W,
+template <typename S, int REG>
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_materialize(MfParams P, const S *__restrict__ xs,
+                                                             S *__restrict__ xd, const S *__restrict__ ps,
+                                                             S *__restrict__ pd, const double *__restrict__ W,
                                                              const CpCtrl *__restrict__ ctrl, int cbuf) {
     __shared__ double tiles[CP_WAVES * 16 * CP_TS];
     __shared__ double Wl[CP_KMAX * CP_KMAX];
@@ -374,10 +374,10 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_materialize(MfParams P, const d
         load_y3_apply_W(ps + (size_t)(K + NY2 * K) * fs, fs, e, valid, K, Wl, tile, lane);
         if (valid) {
             for (int k = 0; k < K; ++k) {
-                xd[(size_t)(2 * k) * fs + e] = xs[(size_t)(2 * k) * fs + e] - cx;
-                xd[(size_t)(2 * k + 1) * fs + e] = xs[(size_t)(2 * k + 1) * fs + e] - cy;
+                xd[(size_t)(2 * k) * fs + e] = (S)((double)xs[(size_t)(2 * k) * fs + e] - cx);
+                xd[(size_t)(2 * k + 1) * fs + e] = (S)((double)xs[(size_t)(2 * k + 1) * fs + e] - cy);
                 xd[(size_t)(2 * K + k) * fs + e] = xs[(size_t)(2 * K + k) * fs + e];
-                pd[(size_t)(K + NY2 * K + k) * fs + e] = tile[k * CP_TS + lane];
+                pd[(size_t)(K + NY2 * K + k) * fs + e] = (S)tile[k * CP_TS + lane];
             }
             if (ps != pd)
                 for (int f = 0; f < K + NY2 * K; ++f) pd[(size_t)f * fs + e] = ps[(size_t)f * fs + e];
@@ -410,9 +410,10 @@ struct WarpParams {
 };
 
 // one thread per (pixel, image); u is read from x fields [2k], [2k+1] (true values: canonical state)
+template <typename S>
 __global__ __launch_bounds__(CP_BLOCK) void k_mf_warp(WarpParams P, const double *__restrict__ imgs,
-                                                      const double *__restrict__ x, double *__restrict__ Tu,
-                                                      double *__restrict__ g, double *__restrict__ b) {
+                                                      const S *__restrict__ x, S *__restrict__ Tu,
+                                                      S *__restrict__ g, S *__restrict__ b) {
     const long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x;
     if (gid >= (long long)P.npix * P.K) return;
     const int k = (int)(gid / P.npix), q = (int)(gid - (long long)k * P.npix);
@@ -422,14 +423,17 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_warp(WarpParams P, const double
     const double py = __dadd_rn(__dadd_rn(P.om2, __dmul_rn(P.hy, (double)(P.j_off + j) + 0.5)), uy);
     double val, dx, dy;
     bilinear_tap(imgs + (size_t)k * P.ifs, P.mi, P.ni, px, py, P.inv_h1, P.inv_h2, val, dx, dy);
-    Tu[(size_t)k * P.fs + e] = val;
-    g[(size_t)(2 * k) * P.fs + e] = dx;
-    g[(size_t)(2 * k + 1) * P.fs + e] = dy;
-    b[(size_t)k * P.fs + e] = val - (dx * ux + dy * uy);               // NNE/mf_nn_tv...:167-168
+    Tu[(size_t)k * P.fs + e] = (S)val;
+    g[(size_t)(2 * k) * P.fs + e] = (S)dx;
+    g[(size_t)(2 * k + 1) * P.fs + e] = (S)dy;
+    // fp32 storage: b is formed from the rounded gradient, the one the iteration multiplies with
+    const double dxs = rnd<S>(dx), dys = rnd<S>(dy);
+    b[(size_t)k * P.fs + e] = (S)(val - (dxs * ux + dys * uy));        // NNE/mf_nn_tv...:167-168
 }
 
 // ---- Gram of (B*field)*Vm for accurate singular values (nu_0, SV_history) -----------------------------
-__global__ __launch_bounds__(CP_BLOCK) void k_mf_gram_field(MfParams P, const double *__restrict__ field,
+template <typename S>
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_gram_field(MfParams P, const S *__restrict__ field,
                                                             const double *__restrict__ Vm,
                                                             double *__restrict__ part) {
     __shared__ double tiles[CP_WAVES * 16 * CP_TS];
@@ -490,9 +494,10 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_sv_eig(int nblk, const double *
 
 // ---- power iteration of NNE/matrix_norm.m on A = [-grad T, I; D|Lap, 0; 0, B] -------------------------------
 // y = A*(scale*x)
-template <int REG>
+// SG: storage type of the gradient field (the vectors of the power iteration are doubles in every mode)
+template <typename SG, int REG>
 __global__ __launch_bounds__(CP_BLOCK) void k_mf_applyA(MfParams P, const double *__restrict__ x, double scale,
-                                                        const double *__restrict__ g, double *__restrict__ y) {
+                                                        const SG *__restrict__ g, double *__restrict__ y) {
     const int K = P.K, m = P.m, fs = P.fs;
     const bool linear = (P.bc == 1), neumann = (P.bc == 0);
     const int NY2 = (REG == 0) ? 4 : 2;
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_applyA(MfParams P, const double
             const double *ux = x + (size_t)(2 * k) * fs + e, *uy = x + (size_t)(2 * k + 1) * fs + e;
             const double L = scale * x[(size_t)(2 * K + k) * fs + e];
             const double u0 = scale * ux[0], v0 = scale * uy[0];
-            y[(size_t)k * fs + e] = -(g[(size_t)(2 * k) * fs + e] * u0 + g[(size_t)(2 * k + 1) * fs + e] * v0) + L;
+            y[(size_t)k * fs + e] = -((double)g[(size_t)(2 * k) * fs + e] * u0 + (double)g[(size_t)(2 * k + 1) * fs + e] * v0) + L;
             y[(size_t)(K + NY2 * K + k) * fs + e] = L - mean;
             if (REG == 0) {
                 const int oi = last_i ? -1 : 1, oj = last_j ? -m : m;
@@ -536,9 +541,9 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_applyA(MfParams P, const double
 }
 
 // xo = A'*y and per-block partial sums of ||xo||^2 (part[blk*CP_PSTRIDE + 0])
-template <int REG>
+template <typename SG, int REG>
 __global__ __launch_bounds__(CP_BLOCK) void k_mf_applyAT(MfParams P, const double *__restrict__ y,
-                                                         const double *__restrict__ g, double *__restrict__ xo,
+                                                         const SG *__restrict__ g, double *__restrict__ xo,
                                                          double *__restrict__ part) {
     __shared__ double red[CP_WAVES * 2];
     const int K = P.K, m = P.m, fs = P.fs;

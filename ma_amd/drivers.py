@@ -160,7 +160,10 @@ def num_levels(m, n):
     return int(min(math.floor(math.log2(m) - 5), math.floor(math.log2(n) - 5))) + 1   # mf_nn_tv...:59
 
 
-def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True, single_level=False):
+def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True, single_level=False,
+              fp32=False):
+    """fp32=True: CP_FLAG_FP32 storage mode of the engine (fields as float, arithmetic in double); not part of the
+    reference's optPara, results agree with the fp64 mode to about 1e-4 relative."""
     k = len(img)
     img = [normalize(im) for im in img]
     m, n = img[0].shape
@@ -184,7 +187,7 @@ def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_
         for (ml, nl) in sizes:
             h_grid = ((omega[1] - omega[0]) / ml, (omega[3] - omega[2]) / nl)          # (:88)
             engines.append(E.Engine(model, ml, nl, k=k, bc=optPara["bc"], h=h_grid, omega=omega, mu=optPara["mu"],
-                                    device=device))
+                                    device=device, flags=E.FLAG_FP32 if fp32 else 0))
         engines[-1].set_images(np.concatenate([_vecF(im) for im in img]))
         for lev in range(levels - 1, 0, -1):
             engines[lev].downsample_to(engines[lev - 1])

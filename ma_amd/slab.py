@@ -24,14 +24,16 @@ class Partition:
 
 
 class SlabSolver:
-    def __init__(self, model, m, n, k, bc, h, omega, mu, device, part):
+    def __init__(self, model, m, n, k, bc, h, omega, mu, device, part, flags=0):
         self.part = part
         self.m, self.n, self.k = m, n, k
         # CP_FORCE_SLAB_PATH=1 (tests): run the multi-GPU driver on a single rank too, so that the RCCL code path
         # (device-tensor all-gather, stream hand-over) is exercised on a one-GPU box
         if part.world == 1 and os.environ.get("CP_FORCE_SLAB_PATH", "0") != "1":
-            self.eng = E.Engine(model, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu, device=device)
+            self.eng = E.Engine(model, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu, device=device, flags=flags)
         else:
+            if flags:
+                raise ValueError("row slabs run in the fp64 mode only")
             from .slab_mg import MultiGpuEngine
             self.eng = MultiGpuEngine(model, m, n, k, bc, h, omega, mu, device, part)
 

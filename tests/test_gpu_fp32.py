@@ -1,5 +1,5 @@
-"""fp32 mode of the pairwise models (CP_FLAG_FP32: float storage, fp64 arithmetic) against the fp64 mode and the oracle:
-north_star tolerance 1e-4 relative on the displacement field and the final energy."""
+"""fp32 mode of the pairwise and mf_nn models (CP_FLAG_FP32: float storage, fp64 arithmetic) against the fp64 mode and
+the oracle: north_star tolerance 1e-4 relative on the displacement field and the final energy."""
 import numpy as np
 import pytest
 
@@ -89,4 +89,85 @@ def test_fp32_denoise_and_batch():
         assert np.array_equal(one.primal(), xb[s])
         one.close()
     with pytest.raises(E.CpEngineError, match="unsupported"):
-        E.Engine(E.MODEL_MF_NN_TV, 16, 16, k=3, flags=E.FLAG_FP32)
+        E.Engine(E.MODEL_VAR_TV, 16, 16, k=3, flags=E.FLAG_FP32)
+    with pytest.raises(E.CpEngineError, match="unsupported"):
+        E.Engine(E.MODEL_MF_NN_TV, 16, 8, k=3, n_global=16, j_offset=0, flags=E.FLAG_FP32)
+
+
+@pytest.mark.parametrize("reg,bc,m,n,k", [("tv", "neumann", 48, 40, 3), ("tv", "linear", 33, 50, 4),
+                                          ("curvature", "dirichlet", 40, 36, 3), ("tv", "neumann", 64, 64, 16)])
+def test_fp32_mf_nn_matches_oracle(reg, bc, m, n, k):
+    """mf_nn models in the fp32 storage mode: 40 iterations from a non-trivial start against the fp64 oracle."""
+    from ma_amd import engine as E
+    from oracle import drivers as od
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    from test_gpu_mfnn import _setup
+    imgs, u0, omega, h, A, b, T_u, gs = _setup(m, n, k, reg, bc)
+    mu = 0.2 if reg == "tv" else 20.0
+    nu, tau = 2.0 * k, 0.3 if reg == "tv" else 0.12
+    sigma = tau
+    kmn = k * m * n
+    ncomp = 6 if reg == "tv" else 4
+    rng = np.random.default_rng(5)
+    x0 = np.concatenate([u0.reshape(-1), 0.5 * T_u.reshape(-1, order="F")])
+    y0 = 0.01 * rng.standard_normal(ncomp * kmn)
+    Fh = lambda y, c, nargout: od.mf_nn_F(y, b, k, h, mu, nu, sigma, c, nargout, reg)
+    Gh = lambda x, c, nargout: od.mf_nn_G(x, (m, n, k), c, nargout)
+    iters = 40
+    xr, yr, phr, dhr = cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, sigma, iters, 1e-3)
+    model = E.MODEL_MF_NN_TV if reg == "tv" else E.MODEL_MF_NN_CURV
+    eng = E.Engine(model, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu, flags=E.FLAG_FP32)
+    eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+    eng.set_primal(x0)
+    eng.linearize()
+    Tg, gg, bg = eng.get_linearization()
+    assert _rel(bg, b) < 1e-6 and _rel(Tg, T_u.reshape(-1, order="F")) < 1e-6
+    sv32 = eng.singular_values(0)
+    ne32, _ = eng.norm_estimate(None)
+    eng.set_dual(y0)
+    eng.set_nu(nu)
+    eng.solve(1.0, tau, sigma, iters, 1e-3)
+    x, y = eng.primal(), eng.dual()
+    ph, dh = eng.history()
+    svL = eng.singular_values(1)
+    eng.close()
+    # the same quantities in the fp64 mode
+    e64 = E.Engine(model, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu)
+    e64.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+    e64.set_primal(x0)
+    e64.linearize()
+    sv64 = e64.singular_values(0)
+    ne64, _ = e64.norm_estimate(None)
+    e64.close()
+    print("fp32 x", _rel(x, xr), "u", _rel(x[:2 * kmn], xr[:2 * kmn]), "y", _rel(y, yr),
+          "E", abs(ph[-1, 0] - phr[-1, 0]) / abs(phr[-1, 0]), abs(dh[-1, 0] - dhr[-1, 0]) / abs(dhr[-1, 0]))
+    assert ph.shape == phr.shape
+    assert _rel(x[: 2 * kmn], xr[: 2 * kmn]) < TOL32          # displacement field
+    assert _rel(x, xr) < TOL32
+    assert _rel(y, yr) < TOL32
+    assert abs(ph[-1, 0] - phr[-1, 0]) <= TOL32 * abs(phr[-1, 0])   # final energy
+    assert abs(dh[-1, 0] - dhr[-1, 0]) <= TOL32 * abs(dhr[-1, 0])
+    assert _rel(x, xr) > 1e-12                                 # a different storage precision indeed
+    assert np.array_equal(x, x.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(sv32, sv64, rtol=1e-5, atol=1e-6 * sv64[0])   # the mean-free block has one zero value
+    assert abs(ne32 - ne64) <= 1e-6 * ne64
+    Lr = xr[2 * kmn:].reshape(m * n, k, order="F")
+    svr = np.linalg.svd(Lr - Lr.mean(axis=1, keepdims=True), compute_uv=False)
+    np.testing.assert_allclose(svL, svr, rtol=1e-4, atol=1e-4 * svr[0])
+
+
+def test_fp32_mf_nn_multilevel_driver():
+    """mf_nn_tv_registration_no_ref_ml in the fp32 mode (prolongation, downsampling, power iteration, nu rule) against
+    the fp64 mode of the same driver."""
+    from ma_amd import synth
+    from ma_amd.drivers import mf_nn_tv_registration_no_ref_ml
+    k, m, n = 4, 80, 72
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    optPara = dict(theta=1.0, maxIter=60, tol=1e-3, outerIter=[3, 2], mu=0.1, nu_factor=[0.9, 0.95], bc="linear", doPlots=False)
+    u64, L64, SV64 = mf_nn_tv_registration_no_ref_ml([imgs[i] for i in range(k)], optPara)
+    u32, L32, SV32 = mf_nn_tv_registration_no_ref_ml([imgs[i] for i in range(k)], optPara, fp32=True)
+    ru = _rel(u32[-1][1], u64[-1][1])
+    rl = _rel(L32[-1][1], L64[-1][1])
+    print("driver fp32 vs fp64: u", ru, "L", rl)
+    assert ru < 10 * TOL32 and rl < TOL32     # two levels, five re-linearisations: rounding differences compound
+    np.testing.assert_allclose(SV32[-1], SV64[-1], rtol=1e-3, atol=1e-4 * SV64[-1].max())
