@@ -124,6 +124,13 @@ int cp_set_dual(cp_handle h, const double *y0);
 int cp_linearize(cp_handle h, const double *u0);
 /* copies of the linearisation for unit parity: T(u0) (m*n*k), grad (m*n x 2 per image), b  */
 int cp_get_linearization(cp_handle h, double *T_u, double *grad, double *b);
+/* the operators' data arguments given directly instead of through a warp: grad = g and b = the I / b argument of
+ * NNE/SAD.m:1 (SAD(L, I, mu, sigma, flag)), PDO/SAD_registration.m:40 / PDO/SSD_registration.m:44 (b = T(u0) -
+ * grad T * u0 - R), NNE/mf_nn_tv...:167-168; T_u (may be NULL) only feeds cp_singular_values(0). Layout as returned
+ * by cp_get_linearization; the variance models centre b (B*b, NNE/var_tv...:153-154) on the device as cp_linearize
+ * does. Full-domain handles, every model but the denoiser. Lets a caller evaluate the operators on chosen inputs
+ * (unit parity of a8-a18) and re-use a linearisation computed elsewhere.                  */
+int cp_set_linearization(cp_handle h, const double *T_u, const double *grad, const double *b);
 
 /* --- mf_nn only --------------------------------------------------------------------------
  * radius nu of the nuclear-norm ball (NNE/mf_nn_tv...:171-180 keeps the schedule on the host) */
@@ -136,6 +143,13 @@ int cp_singular_values(cp_handle h, int which, double *sv);
  * vector (length 3kmn) or NULL for the engine's deterministic start
  * x_i = ((i*2654435761) mod 2^32)/2^31 - 1. Returns e(end) and the number of iterations.    */
 int cp_norm_estimate(cp_handle h, const double *x0, double *est, int32_t *iters);
+/* y = A*x and x = A'*y for the handle's block operator (mf_nn: NNE/mf_nn_tv...:183-188, [-grad T, I; D | Lap, 0;
+ * 0, B]; var: NNE/var_tv...:154-161) -- the products of PDO/chambolle_pock.m:162,165 on caller-supplied vectors
+ * (x: 3kmn or 2kmn, y: the dual length). grad T = 0 until the first linearisation, so that D, D', the Laplacian and
+ * B (NNE/finite_difference_operator.m:29-50, NNE/discrete_laplacian.m:23-46, NNE/mean_free_operator.m:20) can be
+ * applied on their own. fp64 in every storage mode; the solver state (x, y) is left untouched.                  */
+int cp_apply_A(cp_handle h, const double *x, double *y);
+int cp_apply_At(cp_handle h, const double *y, double *x);
 
 /* --- solve: PDO/chambolle_pock.m:54-228 for the handle's (F, G, K) ----------------------- */
 int cp_solve(cp_handle h, double theta, double tau, double sigma, int32_t max_iter, double tol,

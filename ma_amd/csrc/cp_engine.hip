@@ -468,6 +468,24 @@ extern "C" int cp_get_linearization(cp_handle h, double *T_u, double *grad, doub
     return CP_OK;
 }
 
+extern "C" int cp_set_linearization(cp_handle h, const double *T_u, const double *grad, const double *b) {
+    if (!h || !grad || !b) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_set_linearization needs a handle, grad and b");
+    HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
+    if (!h->mf && h->gt == GT_SAD_DEN) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported the denoiser has no linearisation");
+    if (h->d.n_global != h->nl) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_set_linearization on a slab");
+    if (T_u) CPCHK(upload_fields(h, h->Tu, T_u, h->K * h->batch));
+    CPCHK(upload_fields(h, h->g, grad, 2 * h->K * h->batch));
+    CPCHK(upload_fields(h, h->b, b, h->K * h->batch));
+    if (h->var) {
+        hipLaunchKernelGGL(k_var_center_b, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, mf_params(h, 1.0, 1.0, 1.0), h->b);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->linearized = true;
+    return CP_OK;
+}
+
 extern "C" int cp_set_nu(cp_handle h, double nu) {
     if (!h || !h->mf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_set_nu needs an mf_nn handle");
     if (!(nu > 0.0)) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg nu must be positive");
@@ -505,6 +523,16 @@ static void launch_mf_applyAT(cp_engine *h, const MfParams &P, const double *y, 
         if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyAT<double, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
         else hipLaunchKernelGGL((k_mf_applyAT<double, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
     }
+}
+static void launch_any_applyA(cp_engine *h, const MfParams &P, const double *x, double scale, double *y) {
+    if (h->var && h->reg == 0) hipLaunchKernelGGL((k_var_applyA<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
+    else if (h->var) hipLaunchKernelGGL((k_var_applyA<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
+    else launch_mf_applyA(h, P, x, scale, y);
+}
+static void launch_any_applyAT(cp_engine *h, const MfParams &P, const double *y, double *xo) {
+    if (h->var && h->reg == 0) hipLaunchKernelGGL((k_var_applyAT<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
+    else if (h->var) hipLaunchKernelGGL((k_var_applyAT<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
+    else launch_mf_applyAT(h, P, y, xo);
 }
 // the power iteration's vectors move between host and device as doubles in every mode
 struct Fp64Transfers {
@@ -587,16 +615,8 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
     int i = 0;
     while (i < 2 || std::fabs(e[i - 1] - e[i - 2]) > tol * e[i - 1]) {   // :25
         ++i;
-        if (h->var && h->reg == 0) {
-            hipLaunchKernelGGL((k_var_applyA<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa, scale, h->g, yb);
-            hipLaunchKernelGGL((k_var_applyAT<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, yb, h->g, xb, h->part);
-        } else if (h->var) {
-            hipLaunchKernelGGL((k_var_applyA<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xa, scale, h->g, yb);
-            hipLaunchKernelGGL((k_var_applyAT<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, yb, h->g, xb, h->part);
-        } else {
-            launch_mf_applyA(h, P, xa, scale, yb);
-            launch_mf_applyAT(h, P, yb, xb);
-        }
+        launch_any_applyA(h, P, xa, scale, yb);
+        launch_any_applyAT(h, P, yb, xb);
         HIPCHK(hipGetLastError());
         double ss;
         CPCHK(sumsq_partials(ss));
@@ -613,6 +633,36 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
     if (iters) *iters = i;
     return CP_OK;
 }
+
+// y = A*x / x = A'*y on caller-supplied vectors, staged in the spare buffers as the power iteration does
+static int apply_operator(cp_handle h, bool transpose, const double *in, double *out) {
+    if (!h || !h->mf || !in || !out) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_apply_A / cp_apply_At need an mf_nn or var handle and two buffers");
+    HIPCHK(hipSetDevice(h->d.device));
+    CP_NOT_ITERATING(h);
+    if (h->d.n_global != h->nl) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_apply_A / cp_apply_At on a slab");
+    const MfParams P = mf_params(h, 1.0, 1.0, 1.0);
+    double *xa = h->X[1], *yb = h->P[1];   // spare buffers (state lives in X[0], P[0]); their halo columns stay zero
+    Fp64Transfers t(h);
+    if (!transpose) {
+        HIPCHK(hipMemsetAsync(xa, 0, sizeof(double) * h->xN, h->stream));
+        CPCHK(upload_fields(h, xa, in, h->nxf));
+        launch_any_applyA(h, P, xa, 1.0, yb);
+        HIPCHK(hipGetLastError());
+        CPCHK(download_fields(h, yb, out, h->npf));
+    } else {
+        HIPCHK(hipMemsetAsync(yb, 0, sizeof(double) * h->pN, h->stream));
+        CPCHK(upload_fields(h, yb, in, h->npf));
+        launch_any_applyAT(h, P, yb, xa);
+        HIPCHK(hipGetLastError());
+        CPCHK(download_fields(h, xa, out, h->nxf));
+    }
+    HIPCHK(hipMemsetAsync(h->X[1], 0, sizeof(double) * h->xN, h->stream));
+    HIPCHK(hipMemsetAsync(h->P[1], 0, sizeof(double) * h->pN, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CP_OK;
+}
+extern "C" int cp_apply_A(cp_handle h, const double *x, double *y) { return apply_operator(h, false, x, y); }
+extern "C" int cp_apply_At(cp_handle h, const double *y, double *x) { return apply_operator(h, true, y, x); }
 
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
