@@ -55,6 +55,9 @@ def _load():
         "cp_set_dual": [vp, dp],
         "cp_linearize": [vp, dp],
         "cp_get_linearization": [vp, dp, dp, dp],
+        "cp_set_linearization": [vp, dp, dp, dp],
+        "cp_apply_A": [vp, dp, dp],
+        "cp_apply_At": [vp, dp, dp],
         "cp_set_nu": [vp, C.c_double],
         "cp_singular_values": [vp, C.c_int, dp],
         "cp_norm_estimate": [vp, dp, dp, C.POINTER(C.c_int32)],
@@ -95,7 +98,7 @@ def _load():
 
 lib = _load()
 EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_images", "cp_set_primal", "cp_set_dual",
-            "cp_linearize", "cp_get_linearization", "cp_set_nu", "cp_singular_values", "cp_norm_estimate", "cp_solve",
+            "cp_linearize", "cp_get_linearization", "cp_set_linearization", "cp_apply_A", "cp_apply_At", "cp_set_nu", "cp_singular_values", "cp_norm_estimate", "cp_solve",
             "cp_get_result", "cp_get_history", "cp_get_primal", "cp_get_dual", "cp_get_images", "cp_prolong",
             "cp_downsample", "cp_iterate", "cp_iterate_begin", "cp_iterate_steps", "cp_iterate_end", "cp_sync",
             "cp_kernel_time_ms", "cp_set_stream", "cp_mg_partial_len",
@@ -194,6 +197,27 @@ class Engine:
         b = np.empty(kk * self.m * self.n)
         _chk(lib.cp_get_linearization(self._h, _dptr(T), _dptr(g), _dptr(b)))
         return T, g, b
+
+    def set_linearization(self, T_u, grad, b):
+        """grad T and b given directly (the data arguments of the operators); T_u may be None"""
+        T_u, grad, b = _f64(T_u), _f64(grad), _f64(b)
+        _chk(lib.cp_set_linearization(self._h, _dptr(T_u), _dptr(grad), _dptr(b)))
+
+    def apply_A(self, x):
+        x = _f64(x)
+        if x.size != self.nx:
+            raise CpEngineError(f"cpengine:badArg x has {x.size} entries, expected {self.nx}")
+        y = np.empty(self.ny)
+        _chk(lib.cp_apply_A(self._h, _dptr(x), _dptr(y)))
+        return y
+
+    def apply_At(self, y):
+        y = _f64(y)
+        if y.size != self.ny:
+            raise CpEngineError(f"cpengine:badArg y has {y.size} entries, expected {self.ny}")
+        x = np.empty(self.nx)
+        _chk(lib.cp_apply_At(self._h, _dptr(y), _dptr(x)))
+        return x
 
     def set_nu(self, nu):
         _chk(lib.cp_set_nu(self._h, float(nu)))

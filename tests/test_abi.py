@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     txt = open(os.path.join(ROOT, "include", "cpengine.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(cp_[a-z_0-9]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(cp_[A-Za-z_0-9]+)\s*\(", txt)))
 
 
 def test_header_symbols_exported():
