@@ -44,3 +44,32 @@ for tag, model, el, mu in (("c4", E.MODEL_MF_NN_CURV, 31, 20.0), ("var", E.MODEL
     eng.set_primal(np.concatenate([u0, np.zeros(k*m*n)]) if tag == "c4" else u0); eng.linearize()
     if tag == "c4": eng.set_nu(30.0)
     run(("C4 NN-curvature" if tag == "c4" else "var-TV") + " 4096^2 x 16", eng, 1.0, 0.1, 0.1, 20, el * 8.0 * k * m * n); eng.close()
+if "c1" in which:
+    # C1: TV-L1 denoising of Data/rect1.png (fixture copy) with the committed salt & pepper mask, PDO/test_TV_L1_denoising.m
+    from ma_amd import drivers as D
+    gd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    f = np.load(os.path.join(gd, "pairwise_e2e.npz"))
+    noisy = f["c1_noisy"]
+    D.tv_l1_denoising(noisy, lam=1.5, tau=0.02, maxIter=1000, tol=1e-5)                # warm-up (module load, first launches)
+    t0 = time.perf_counter(); x, y, ph, dh, sigma = D.tv_l1_denoising(noisy, lam=1.5, tau=0.02, maxIter=1000, tol=1e-5)
+    dt = time.perf_counter() - t0
+    its = ph.shape[0] - 1
+    print(json.dumps({"workload": f"C1 TV-L1 denoise {noisy.shape[0]}x{noisy.shape[1]} (whole call, launch-bound)",
+                      "iterations": its, "seconds": dt, "it_per_s": its / dt}), flush=True)
+if "c3" in which:
+    # C3: mf_nn_tv_registration_no_ref_ml, K = 10 synthetic 1024^2 templates, all levels (whole driver, wall clock)
+    from ma_amd import drivers as D
+    m = n = 1024; k = 10
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    # parameters of the synthetic demo, NNE/demo_mf_nn_tv_registration_no_ref_ml.m:34-41
+    optPara = dict(theta=1.0, maxIter=2000, tol=1e-3, outerIter=[16, 2], mu=0.2, nu_factor=[0.9, 0.9], bc="neumann", doPlots=False)
+    for tag, fp32 in (("fp64", False), ("fp32 storage", True)):
+        keep = {}
+        t0 = time.perf_counter()
+        u, L, SV = D.mf_nn_tv_registration_no_ref_ml([imgs[i] for i in range(k)], optPara, keep=keep, download_all=False, fp32=fp32)
+        dt = time.perf_counter() - t0
+        its = sum(v["iterations"] for v in keep.values())
+        pw = sum(v["n_power"] for v in keep.values())
+        print(json.dumps({"workload": f"C3 mf_nn_tv_registration_no_ref_ml K=10 1024^2, {D.num_levels(m, n)} levels, {tag}",
+                          "seconds": dt, "cp_iterations": its, "power_iterations": pw, "outer_iterations": len(keep),
+                          "cp_it_per_s_whole_driver": its / dt}), flush=True)
