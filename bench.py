@@ -54,8 +54,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--cols", type=int, default=0, help="image columns (default: --size); a slab-shaped problem for tuning")
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--reg", default="tv", choices=["tv", "curvature"])
+    ap.add_argument("--workload", default="nn", choices=["nn", "batch"],
+                    help="nn: the headline (row slabs over the ranks); batch: BASELINE config 5, 256 independent TV-L2 "
+                         "512^2 registrations sharded over the ranks, no communication")
+    ap.add_argument("--problems", type=int, default=256)
     ap.add_argument("--fp32", action="store_true", help="CP_FLAG_FP32 storage mode (single GPU); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=1024)
@@ -106,8 +111,93 @@ def cpu_baseline(size, k, iters, reg):
     return iters / dt, dt, 1, "numpy/scipy restatement (reference-shaped: sparse A, 4 SpMV + 3 SVD per iteration)"
 
 
+def main_batch(args):
+    """BASELINE config 5: --problems independent TV-L2 (SSD_registration) pairs of --size^2 (default 512 there) sharded
+    over the ranks; a step = one CP iteration of every problem. No data-path collective."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("CP_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from ma_amd import engine as E, synth
+    from ma_amd.batch import shard_range
+    m = n = args.size if args.size != 4096 else 512
+    P = args.problems
+    p0, p1 = shard_range(P, world, rank)
+    fr = synth.dynamic_test_image(m, n, 2).numpy()
+    # per-problem integer shifts from an LCG (seed 12345), SURVEY.md section 8d
+    st, shifts = 12345, []
+    for _ in range(P):
+        st = (1103515245 * st + 12345) % (1 << 31)
+        shifts.append(st % 9 - 4)
+    T = np.concatenate([np.roll(fr[1], shifts[p], axis=0).reshape(-1, order="F") for p in range(p0, p1)])
+    R = np.tile(fr[0].reshape(-1, order="F"), p1 - p0)
+    esz = 4.0 if args.fp32 else 8.0
+    eng = E.Engine(E.MODEL_TV_L2_REG, m, n, lam=50.0, batch=p1 - p0, device=local_rank, flags=E.FLAG_FP32 if args.fp32 else 0)
+    eng.set_images(T, R)
+    eng.set_primal(np.zeros(2 * m * n * (p1 - p0)))
+    eng.linearize()
+    tau = 4.0
+    sigma = (1 - 1e-4) / (8 * tau)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.iterate_begin(1.0, tau, sigma, args.warmup + args.steps)
+    eng.iterate_steps(args.warmup)
+    eng.sync()
+    for pss in ("dual", "primal", "fin"):
+        eng.kernel_time_ms(pss)
+    barrier()
+    t0 = time.perf_counter()
+    eng.iterate_steps(args.steps)
+    eng.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.iterate_end()
+    times = {pss: eng.kernel_time_ms(pss) for pss in ("dual", "primal", "fin")}
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        dual_s = times["dual"][0] / max(times["dual"][1], 1) * 1e-3
+        dual_bytes = 12 * esz * m * n * (p1 - p0)                 # dual pass: 12 of the 23 elements per pixel
+        achieved = dual_bytes / dual_s / 1e9 if dual_s > 0 else 0.0
+        out = {"metric": f"problem-iterations/sec, batch of {P} TV-L2 registrations {m}^2",
+               "value": P * args.steps / dt, "unit": "problem-iterations/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64" if not args.fp32 else "f64 arithmetic on f32 storage", "data": "synthetic",
+               "config": {"workload": f"{P} x TV_registration + SSD_registration, {m}x{n}, lambda=50, tau=4, one CP iteration "
+                                      f"of every problem per step", "parallelism": f"problems sharded x{world}",
+                          "achieved_GBps_algorithmic": 23 * esz * m * n * P * args.steps / dt / 1e9,
+                          "kernel_ms": {kk: v[0] / max(v[1], 1) for kk, v in times.items()}},
+               "roofline": {"bound": "hbm", "kernel": "k_pw_dual", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": None}}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.workload == "batch":
+        return main_batch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -128,7 +218,8 @@ def main():
     from ma_amd import engine as E, synth
     from ma_amd import slab
 
-    m = n = args.size
+    m = args.size
+    n = args.cols if args.cols > 0 else args.size
     k = args.k
     reg = args.reg
     dev = torch.device("cuda", local_rank)
@@ -195,7 +286,7 @@ def main():
         traffic = None
         try:
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
-            if prof and reg == "tv" and m == 4096 and k == 16 and world == 1 and not args.fp32:
+            if prof and reg == "tv" and m == 4096 and n == 4096 and k == 16 and world == 1 and not args.fp32:
                 traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))["hbm_bytes_per_launch"] / 1e9
         except Exception:
             traffic = None
@@ -208,8 +299,8 @@ def main():
         dual_bytes = ELEMS_DOM[reg] * esz * float(k) * m * part.nl
         achieved = dual_bytes / dual_avg_s / 1e9 if dual_avg_s > 0 else 0.0
         out = {
-            "metric": "CP iterations/sec, NN-TV registration 4096^2 x K=16" if (reg == "tv" and m == 4096 and k == 16 and not args.fp32)
-            else f"CP iterations/sec, NN-{reg} registration {m}^2 x K={k}" + (" (fp32 storage mode)" if args.fp32 else ""),
+            "metric": "CP iterations/sec, NN-TV registration 4096^2 x K=16" if (reg == "tv" and m == 4096 and n == 4096 and k == 16 and not args.fp32)
+            else f"CP iterations/sec, NN-{reg} registration {m}x{n} x K={k}" + (" (fp32 storage mode)" if args.fp32 else ""),
             "value": its,
             "unit": "iterations/s",
             "n_gpus": world,

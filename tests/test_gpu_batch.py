@@ -1,0 +1,19 @@
+"""Batch mode sharded over ranks (BASELINE config 5) on ONE GPU: 2 and 3 gloo ranks against the single-handle batch."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,P,fp32", [(2, 7, "0"), (3, 8, "1"), (3, 2, "0")])
+def test_batch_shards_match_single_handle(world, P, fp32):
+    env = dict(os.environ, BATCH_P=str(P), BATCH_FP32=fp32, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29440 + world), os.path.join(ROOT, "tests", "batch_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "batch shards == single handle" in r.stdout

@@ -59,3 +59,51 @@ def test_slab_comm_gloo(world):
     results = mgr.dict()
     mp.spawn(_worker, args=(world, 29510 + world, results), nprocs=world, join=True)
     assert all(results[r] for r in range(world)) and len(results) == world
+
+
+def _batch_worker(rank, world, port, results):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from ma_amd import batch
+
+    class Stub:   # stands in for the GPU shard solver: "solves" problem p as a function of its images only
+        def __init__(self, R, T, *a, **kw):
+            self.R, self.T = np.asarray(R), np.asarray(T)
+
+        def run(self, maxIter, numSteps, tol=1e-3):
+            u = np.stack([np.concatenate([r.ravel() + 2 * t.ravel(), r.ravel() - t.ravel()]) for r, t in zip(self.R, self.T)]) \
+                if len(self.R) else np.zeros((0, 2 * self.R.shape[1] * self.R.shape[2]))
+            return u, np.full((len(self.R), numSteps), maxIter, dtype=np.int64)
+
+        def close(self):
+            pass
+
+    batch.BatchRegistration = Stub
+    P, m, n = 7, 3, 2
+    rng = np.random.default_rng(0)
+    R, T = rng.standard_normal((P, m, n)), rng.standard_normal((P, m, n))
+    u, its = batch.tv_registration_batch(R, T, 1.0, 1.0, 5, 2)
+    want = np.stack([np.concatenate([r.ravel() + 2 * t.ravel(), r.ravel() - t.ravel()]) for r, t in zip(R, T)])
+    ok = np.array_equal(u, want) and its.shape == (P, 2)
+    u_loc, _, (p0, p1) = batch.tv_registration_batch(R, T, 1.0, 1.0, 5, 2, gather=False)
+    ok &= (p0, p1) == batch.shard_range(P, world, rank) and np.array_equal(u_loc, want[p0:p1])
+    results[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_batch_sharding_gloo(world):
+    from ma_amd.batch import shard_range
+    for P in (1, 2, 7, 256):
+        for w in (1, 2, 3, 8):
+            rngs = [shard_range(P, w, r) for r in range(w)]
+            assert rngs[0][0] == 0 and rngs[-1][1] == P
+            assert all(rngs[i][1] == rngs[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in rngs) - min(b - a for a, b in rngs) <= 1
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_batch_worker, args=(world, 29520 + world, results), nprocs=world, join=True)
+    assert all(results[r] for r in range(world))
