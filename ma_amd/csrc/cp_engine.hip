@@ -76,6 +76,9 @@ struct cp_engine {
     int hist_rows = 0;   // rows allocated (per problem)
     int hcols = 0;
     int nblk = 0;
+    int pw_strip = 0;        // columns per wave of k_pw_march (0: k_pw_fused), pw_groups row groups of 63, pw_waves waves
+    int pw_groups = 0, pw_waves = 0, pw_grid = 0;
+    bool pw_split = false;   // tuning aid (CP_TUNE_PW_SPLIT=1): pairwise models on the split passes instead of k_pw_fused
     int fused_tw = 1;    // image columns per workgroup tile of k_mf_fused_tv
     int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU resident: two LDS tiles per wave)
     bool linearized = false, has_nu = false, has_images = false;
@@ -322,6 +325,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         h->fused_tw = 1;
         if (const char *ev = getenv("CP_TUNE_FUSED_TW")) h->fused_tw = (atoi(ev) == 4) ? 4 : (atoi(ev) == 2 ? 2 : 1);   // tuning knobs
         h->nblk_fused = std::max(1, std::min(fused_tiles(h->m, h->nl, h->fused_tw), CP_FUSED_MAXGRID));
+        if (const char *ev = getenv("CP_TUNE_PW_SPLIT")) h->pw_split = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_FUSED_GRID")) h->nblk_fused = std::max(1, std::min(h->nblk_fused, atoi(ev)));
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
@@ -340,7 +344,19 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
                                h->svout + 16 + 256);
         } else {
             if (h->fp32) HIPCHK(hipMalloc(&h->stage, sizeof(double) * h->npix));
-            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)h->nblk * PW_PSTRIDE * h->batch));
+            // marching kernel when it yields enough waves to fill the chip (8 per SIMD slot would be 8192): strips of
+            // 16 columns, else 8; small problems stay on k_pw_fused (one 256-pixel chunk per workgroup)
+            h->pw_groups = (h->m + 62) / 63;
+            for (int strip : {16, 8}) {
+                const long long waves = (long long)h->pw_groups * ((h->nl + strip - 1) / strip) * h->batch;
+                if (waves >= 8192) { h->pw_strip = strip; break; }
+            }
+            if (const char *ev = getenv("CP_TUNE_PW_STRIP")) h->pw_strip = std::max(0, atoi(ev));
+            if (h->pw_strip > 0) {
+                h->pw_waves = h->pw_groups * ((h->nl + h->pw_strip - 1) / h->pw_strip);
+                h->pw_grid = (h->pw_waves + CP_WAVES - 1) / CP_WAVES;
+            }
+            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(h->nblk, h->pw_grid) * PWF_PSTRIDE * h->batch));
             HIPCHK(hipMalloc(&h->part2, sizeof(double) * (size_t)h->nblk * PW_PSTRIDE * h->batch));
             HIPCHK(hipMalloc(&h->ctrl, sizeof(PwCtrl) * h->batch));
             HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(PwCtrl) * h->batch, h->stream));
@@ -1082,6 +1098,63 @@ static int pw_iterations(cp_engine *h, const PwParams &P, int n0, int count, int
     return CP_OK;
 }
 
+// ---- fused pairwise path: dual step 1 alone, then one k_pw_fused + k_pw_fin_fused per iteration ---------------------
+// state parity: x_n in X[n & 1], v_n in P[n & 1] (as in the split passes); launch n also leaves v_{n+1} in the other P
+template <typename S>
+static void launch_pw_fused_t(cp_engine *h, const PwParams &P, const double *xo_, double *xn_, const double *vin_,
+                              double *vout_) {
+    const PwCtrl *ctrl = (const PwCtrl *)h->ctrl;
+    const S *xo = (const S *)xo_, *vin = (const S *)vin_, *g = (const S *)h->g, *b = (const S *)h->b;
+    S *xn = (S *)xn_, *vout = (S *)vout_;
+    if (h->pw_strip > 0) {
+        dim3 mg(h->pw_grid, h->batch);
+        const int st = h->pw_strip, ng = h->pw_groups, nw = h->pw_waves;
+        if (h->gt == GT_SAD_REG)
+            hipLaunchKernelGGL((k_pw_march<S, GT_SAD_REG>), mg, dim3(CP_BLOCK), 0, h->stream, P, st, ng, nw, xo, xn, vin, vout, g, b, ctrl, h->part);
+        else if (h->gt == GT_SSD_REG)
+            hipLaunchKernelGGL((k_pw_march<S, GT_SSD_REG>), mg, dim3(CP_BLOCK), 0, h->stream, P, st, ng, nw, xo, xn, vin, vout, g, b, ctrl, h->part);
+        else
+            hipLaunchKernelGGL((k_pw_march<S, GT_SAD_DEN>), mg, dim3(CP_BLOCK), 0, h->stream, P, st, ng, nw, xo, xn, vin, vout, b, b, ctrl, h->part);
+        return;
+    }
+    dim3 grid(h->nblk, h->batch);
+    if (h->gt == GT_SAD_REG)
+        hipLaunchKernelGGL((k_pw_fused<S, GT_SAD_REG>), grid, dim3(CP_BLOCK), 0, h->stream, P, xo, xn, vin, vout, g, b, ctrl, h->part);
+    else if (h->gt == GT_SSD_REG)
+        hipLaunchKernelGGL((k_pw_fused<S, GT_SSD_REG>), grid, dim3(CP_BLOCK), 0, h->stream, P, xo, xn, vin, vout, g, b, ctrl, h->part);
+    else
+        hipLaunchKernelGGL((k_pw_fused<S, GT_SAD_DEN>), grid, dim3(CP_BLOCK), 0, h->stream, P, xo, xn, vin, vout, b, b, ctrl, h->part);
+}
+static int pw_fused_start(cp_engine *h, const PwParams &P) {
+    // v_1 = prox_{sigma F*}(v_0 + sigma K xbar_0), xbar_0 = x_0 (X[1] holds the copy of x_0); its partials give the F*
+    // violation of dual row 1 (the other entries k_pw_fin writes into that row are overwritten by the fused launch 1)
+    launch_pw_dual<0>(h, P, h->X[0], h->X[1], h->P[0], h->P[1]);
+    hipLaunchKernelGGL(k_pw_fin, dim3(h->batch), dim3(PW_FIN_THREADS), 0, h->stream, pw_fin_args(h, -1, -1, 1, 0, 0.0), h->part,
+                       h->part2, (PwCtrl *)h->ctrl, h->hist_p, h->hist_d);
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+static int pw_fused_iterations(cp_engine *h, const PwParams &P, int n0, int count, int check, double tol) {
+    PwCtrl *ctrl = (PwCtrl *)h->ctrl;
+    for (int n = n0 + 1; n <= n0 + count; ++n) {
+        const int cur = n & 1, prv = (n - 1) & 1;   // x_{n-1} in X[prv], v_n in P[cur]
+        CPCHK(timer_begin(h, T_DUAL));
+        if (h->fp32) launch_pw_fused_t<float>(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[prv]);
+        else launch_pw_fused_t<double>(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[prv]);
+        CPCHK(timer_end(h, T_DUAL));
+        PwFusedFinArgs A;
+        A.nblk = h->pw_strip > 0 ? h->pw_grid : h->nblk;
+        A.gt = h->gt; A.n = n; A.check_stop = check; A.hist_rows = h->hist_rows; A.tol = tol;
+        A.lambda = h->d.lambda;
+        CPCHK(timer_begin(h, T_FIN));
+        hipLaunchKernelGGL(k_pw_fin_fused, dim3(h->batch), dim3(PW_FIN_THREADS), 0, h->stream, A, h->part, ctrl, h->hist_p,
+                           h->hist_d);
+        CPCHK(timer_end(h, T_FIN));
+    }
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+
 static int solve_pw(cp_engine *h, double theta, double tau, double sigma, int maxIter, double tol, cp_result *res) {
     if (!h->linearized) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_solve before cp_linearize / cp_set_images");
     CPCHK(ensure_hist(h, maxIter + 2));
@@ -1102,17 +1175,20 @@ static int solve_pw(cp_engine *h, double theta, double tau, double sigma, int ma
     int done = 0;
     bool all_stopped = false;
     const int chunk = 32;
+    if (maxIter > 0 && !h->pw_split) CPCHK(pw_fused_start(h, P));
     while (done < maxIter && !all_stopped) {
         const int cnt = std::min(chunk, maxIter - done);
-        CPCHK(pw_iterations(h, P, done, cnt, 1, tol));
+        if (h->pw_split) CPCHK(pw_iterations(h, P, done, cnt, 1, tol));
+        else CPCHK(pw_fused_iterations(h, P, done, cnt, 1, tol));
         done += cnt;
         HIPCHK(hipMemcpyAsync(hc.data(), ctrl, sizeof(PwCtrl) * h->batch, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         all_stopped = true;
         for (auto &c : hc) all_stopped = all_stopped && c.stop;
     }
-    // F part of primal row maxIter for the problems that ran to the end (stopped ones skip the kernels)
-    {
+    // F part of primal row maxIter for the problems that ran to the end (stopped ones skip the kernels); the fused
+    // launch maxIter has produced it already
+    if (h->pw_split || maxIter == 0) {
         const int cur = maxIter & 1;
         launch_pw_dual<1>(h, P, h->X[cur], h->X[cur ^ 1], h->P[cur], nullptr);
         hipLaunchKernelGGL(k_pw_fin, dim3(h->batch), dim3(PW_FIN_THREADS), 0, h->stream, pw_fin_args(h, maxIter, -1, -1, 0, tol),
@@ -1283,6 +1359,7 @@ extern "C" int cp_iterate_begin(cp_handle h, double theta, double tau, double si
     } else {
         HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(PwCtrl) * h->batch, h->stream));
         HIPCHK(hipMemcpyAsync(h->X[1], h->X[0], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));
+        if (!h->pw_split) CPCHK(pw_fused_start(h, pw_params(h, theta, tau, sigma)));
     }
     h->it_n = 0;
     return CP_OK;
@@ -1305,7 +1382,8 @@ extern "C" int cp_iterate_steps(cp_handle h, int32_t iters) {
         else CPCHK(mf_iterations(h, P, h->it_n, iters, 0, 0.0));
     } else {
         const PwParams P = pw_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
-        CPCHK(pw_iterations(h, P, h->it_n, iters, 0, 0.0));
+        if (h->pw_split) CPCHK(pw_iterations(h, P, h->it_n, iters, 0, 0.0));
+        else CPCHK(pw_fused_iterations(h, P, h->it_n, iters, 0, 0.0));
     }
     HIPCHK(hipEventRecord(t.ev[t.used + 1], h->stream));
     t.used += 2;

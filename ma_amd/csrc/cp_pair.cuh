@@ -1,7 +1,8 @@
 // Fused Chambolle-Pock passes for the pairwise models of PDO/test_TV_L1_registration.m,
 // PDO/test_TV_L2_registration.m and PDO/test_TV_L1_denoising.m.
 //
-// One iteration of PDO/chambolle_pock.m:156-179 = k_pw_dual -> k_pw_primal -> k_pw_fin.
+// One iteration of PDO/chambolle_pock.m:156-179 = k_pw_dual -> k_pw_primal -> k_pw_fin (split passes: row 0, the first
+// dual step) or, in steady state, k_pw_fused (primal step n + dual step n+1) -> k_pw_fin_fused.
 // Layout: fields are m x n column-major with one halo column on each side (fs = m*(n+2));
 // x: NC fields (u_x, u_y | u), v: 2*NC fields (Dx u_c, Dy u_c per component c).
 // blockIdx.y selects the problem of a batch (independent problems of identical shape).
@@ -89,6 +90,108 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_dual(PwParams P, const S *__res
                                      part + ((size_t)prob * gridDim.x + blockIdx.x) * PW_PSTRIDE);
 }
 
+// Primal step and G-side monitors at ONE pixel (e = field index, (i, j) its row / column):
+//   MODE 0: un = prox_{tau G}(u - tau K'v) rounded to the storage type (chambolle_pock.m:165), MODE 1: un = u.
+//   MON: gs[0] += G(un) summand, gs[1] += G*(-K'v) summand, gm[0] = max(G* violation).
+// uo receives u (the iterate before the step). Shared by k_pw_primal and by k_pw_fused, which also evaluates it at the
+// two forward neighbours of a pixel -- same code, same inputs, so the recomputed values equal the stored ones.
+template <typename S, int MODE, int GT, bool MON>
+__device__ __forceinline__ void pw_primal_point(const PwParams &P, const S *__restrict__ xc, const S *__restrict__ v,
+                                                const S *__restrict__ g, const S *__restrict__ b, int e, int i, int j,
+                                                double *un, double *uo, double *gs, double *gm, double *vc = nullptr) {
+    constexpr int NC = (GT == GT_SAD_DEN) ? 1 : 2;
+    const int m = P.m, fs = P.fs;
+    const double tau = P.tau, lam = P.lambda, lt = P.lambda * P.tau;
+    double w[NC], ut[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const S *fx = v + (size_t)(2 * c) * fs + e, *fy = v + (size_t)(2 * c + 1) * fs + e;
+        const double fx0 = fx[0], fy0 = fy[0];
+        if (vc) { vc[2 * c] = fx0; vc[2 * c + 1] = fy0; }                       // v at the pixel, for the caller's dual step
+        const double ax = fwd_diff_adj(fx0, (i >= 1) ? fx[-1] : 0.0, 0.0, i, m, false, P.inv_h1);
+        const double ay = fwd_diff_adj(fy0, (j >= 1) ? fy[-m] : 0.0, 0.0, j, P.n, false, P.inv_h2);
+        w[c] = ax + ay;                                                         // (K'v)_c
+        const double u0 = xc[(size_t)c * fs + e];
+        ut[c] = u0 - tau * w[c];                                                // chambolle_pock.m:165
+        un[c] = u0;
+        uo[c] = u0;
+    }
+    if (GT == GT_SAD_REG) {
+        const double gx = g[e], gy = g[(size_t)fs + e], bb = b[e];
+        const double ngs = gx * gx + gy * gy;
+        if (MODE == 0) {
+            const double phi = bb + (gx * ut[0] + gy * ut[NC - 1]);             // SAD_registration.m:46
+            if (phi < (-tau) * lam * ngs) { un[0] = ut[0] + tau * lam * gx; un[NC - 1] = ut[NC - 1] + tau * lam * gy; }
+            else if (phi > tau * lam * ngs) { un[0] = ut[0] - tau * lam * gx; un[NC - 1] = ut[NC - 1] - tau * lam * gy; }
+            else if (ngs > 1e-14) { const double r = phi / ngs; un[0] = ut[0] - gx * r; un[NC - 1] = ut[NC - 1] - gy * r; }
+            else { un[0] = ut[0]; un[NC - 1] = ut[NC - 1]; }                    // :58-76
+        }
+        if (MODE == 0 && sizeof(S) == 4) { un[0] = (double)(S)un[0]; un[NC - 1] = (double)(S)un[NC - 1]; }
+        if (MON) {
+            gs[0] += fabs(bb + (gx * un[0] + gy * un[NC - 1]));                 // :47
+            // conjugate at -K'v, scaled by 1/lambda  (:86-138)
+            const double zx = -w[0] / lam, zy = -w[NC - 1] / lam;
+            double val, con;
+            if (ngs < 1e-14) {
+                val = -fabs(bb);
+                con = sqrt(zx * zx + zy * zy);
+            } else {
+                const double f = -bb / ngs;
+                val = zx * (f * gx) + zy * (f * gy);
+                const double ng = sqrt(ngs);
+                const double r0 = (gx * zx + gy * zy) / ng, r1 = (-gy * zx + gx * zy) / ng;
+                if (r0 > ng) con = (zx - gx) * (zx - gx) + (zy - gy) * (zy - gy);   // squared (:126)
+                else if (r0 < -ng) con = (zx + gx) * (zx + gx) + (zy + gy) * (zy + gy);   // squared (:130)
+                else con = fabs(r1);                                            // plain (:134)
+            }
+            gs[1] += val;
+            gm[0] = fmax(gm[0], con);
+        }
+    } else if (GT == GT_SSD_REG) {
+        const double gx = g[e], gy = g[(size_t)fs + e], bb = b[e];
+        const double ngs = gx * gx + gy * gy;
+        if (MODE == 0) {
+            // (I + lt*g g') r = ut - lt*g*b     SSD_registration.m:56-63 (2x2 block solve)
+            const double cx = ut[0] - lt * gx * bb, cy = ut[NC - 1] - lt * gy * bb;
+            const double a11 = 1.0 + lt * gx * gx, a12 = lt * gx * gy, a22 = 1.0 + lt * gy * gy;
+            const double det = a11 * a22 - a12 * a12;
+            un[0] = (a22 * cx - a12 * cy) / det;
+            un[NC - 1] = (a11 * cy - a12 * cx) / det;
+        }
+        if (MODE == 0 && sizeof(S) == 4) { un[0] = (double)(S)un[0]; un[NC - 1] = (double)(S)un[NC - 1]; }
+        if (MON) {
+            const double res = (gx * un[0] + gy * un[NC - 1]) + bb;
+            gs[0] += res * res;                                                 // :50-51
+            const double zx = -w[0] / lam, zy = -w[NC - 1] / lam;               // :70
+            const double dd = (zx - bb * gx) * gx + (zy - bb * gy) * gy;
+            double r1 = 0.5 * (dd * dd);                                        // :84
+            double con;
+            if (ngs > 1e-7) {                                                   // :81
+                r1 = r1 / (ngs * ngs);
+                const double ng = sqrt(ngs);
+                con = fabs((-gy / ng) * zx + (gx / ng) * zy);                   // :100-102
+            } else {
+                con = sqrt(zx * zx + zy * zy);                                  // :96
+            }
+            gs[1] += r1 - 0.5 * (bb * bb);                                      // :87
+            gm[0] = fmax(gm[0], con);
+        }
+    } else {
+        const double gi = b[e];
+        if (MODE == 0) {
+            const double d = ut[0] - gi;                                        // SAD_denoise.m:46-52
+            un[0] = (d > lam * tau) ? ut[0] - lam * tau : ((d < (-1.0) * lam * tau) ? ut[0] + lam * tau : gi);
+        }
+        if (MODE == 0 && sizeof(S) == 4) un[0] = (double)(S)un[0];
+        if (MON) {
+            gs[0] += fabs(un[0] - gi);                                          // :40
+            const double z = -w[0] / lam;                                       // :60
+            gs[1] += z * gi;                                                    // :66
+            gm[0] = fmax(gm[0], fabs(z));                                       // :63-65
+        }
+    }
+}
+
 template <typename S, int MODE, int GT>
 __global__ __launch_bounds__(CP_BLOCK) void k_pw_primal(PwParams P, const S *__restrict__ xc_,
                                                         S *__restrict__ xn_, const S *__restrict__ v_,
@@ -103,89 +206,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_primal(PwParams P, const S *__r
     S *xn = xn_ + (size_t)prob * P.nxf * fs;
     const S *v = v_ + (size_t)prob * P.nvf * fs;
     const S *g = g_ + (size_t)prob * 2 * fs, *b = b_ + (size_t)prob * fs;
-    const double tau = P.tau, lam = P.lambda, lt = P.lambda * P.tau;
     double sums[PW_NS] = {0.0, 0.0}, maxs[PW_NM] = {0.0, 0.0};
     for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
         const int j = q / m, i = q - j * m, e = q + m;
-        double w[NC], ut[NC], un[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const S *fx = v + (size_t)(2 * c) * fs + e, *fy = v + (size_t)(2 * c + 1) * fs + e;
-            const double ax = fwd_diff_adj(fx[0], (i >= 1) ? fx[-1] : 0.0, 0.0, i, m, false, P.inv_h1);
-            const double ay = fwd_diff_adj(fy[0], (j >= 1) ? fy[-m] : 0.0, 0.0, j, P.n, false, P.inv_h2);
-            w[c] = ax + ay;                                                         // (K'v)_c
-            const double u0 = xc[(size_t)c * fs + e];
-            ut[c] = u0 - tau * w[c];                                                // chambolle_pock.m:165
-            un[c] = u0;
-        }
-        if (GT == GT_SAD_REG) {
-            const double gx = g[e], gy = g[(size_t)fs + e], bb = b[e];
-            const double ngs = gx * gx + gy * gy;
-            if (MODE == 0) {
-                const double phi = bb + (gx * ut[0] + gy * ut[NC - 1]);             // SAD_registration.m:46
-                if (phi < (-tau) * lam * ngs) { un[0] = ut[0] + tau * lam * gx; un[NC - 1] = ut[NC - 1] + tau * lam * gy; }
-                else if (phi > tau * lam * ngs) { un[0] = ut[0] - tau * lam * gx; un[NC - 1] = ut[NC - 1] - tau * lam * gy; }
-                else if (ngs > 1e-14) { const double r = phi / ngs; un[0] = ut[0] - gx * r; un[NC - 1] = ut[NC - 1] - gy * r; }
-                else { un[0] = ut[0]; un[NC - 1] = ut[NC - 1]; }                    // :58-76
-            }
-            if (MODE == 0 && sizeof(S) == 4) { un[0] = (double)(S)un[0]; un[NC - 1] = (double)(S)un[NC - 1]; }
-            sums[0] += fabs(bb + (gx * un[0] + gy * un[NC - 1]));                   // :47
-            // conjugate at -K'v, scaled by 1/lambda  (:86-138)
-            const double zx = -w[0] / lam, zy = -w[NC - 1] / lam;
-            double val, con;
-            if (ngs < 1e-14) {
-                val = -fabs(bb);
-                con = sqrt(zx * zx + zy * zy);
-            } else {
-                const double f = -bb / ngs;
-                val = zx * (f * gx) + zy * (f * gy);
-                const double ng = sqrt(ngs);
-                const double r0 = (gx * zx + gy * zy) / ng, r1 = (-gy * zx + gx * zy) / ng;
-                if (r0 > ng) con = (zx - gx) * (zx - gx) + (zy - gy) * (zy - gy);   // squared (:126)
-                else if (r0 < -ng) con = (zx + gx) * (zx + gx) + (zy + gy) * (zy + gy);   // squared (:130)
-                else con = fabs(r1);                                                // plain (:134)
-            }
-            sums[1] += val;
-            maxs[0] = fmax(maxs[0], con);
-        } else if (GT == GT_SSD_REG) {
-            const double gx = g[e], gy = g[(size_t)fs + e], bb = b[e];
-            const double ngs = gx * gx + gy * gy;
-            if (MODE == 0) {
-                // (I + lt*g g') r = ut - lt*g*b     SSD_registration.m:56-63 (2x2 block solve)
-                const double cx = ut[0] - lt * gx * bb, cy = ut[NC - 1] - lt * gy * bb;
-                const double a11 = 1.0 + lt * gx * gx, a12 = lt * gx * gy, a22 = 1.0 + lt * gy * gy;
-                const double det = a11 * a22 - a12 * a12;
-                un[0] = (a22 * cx - a12 * cy) / det;
-                un[NC - 1] = (a11 * cy - a12 * cx) / det;
-            }
-            if (MODE == 0 && sizeof(S) == 4) { un[0] = (double)(S)un[0]; un[NC - 1] = (double)(S)un[NC - 1]; }
-            const double res = (gx * un[0] + gy * un[NC - 1]) + bb;
-            sums[0] += res * res;                                                   // :50-51
-            const double zx = -w[0] / lam, zy = -w[NC - 1] / lam;                   // :70
-            const double dd = (zx - bb * gx) * gx + (zy - bb * gy) * gy;
-            double r1 = 0.5 * (dd * dd);                                            // :84
-            double con;
-            if (ngs > 1e-7) {                                                       // :81
-                r1 = r1 / (ngs * ngs);
-                const double ng = sqrt(ngs);
-                con = fabs((-gy / ng) * zx + (gx / ng) * zy);                       // :100-102
-            } else {
-                con = sqrt(zx * zx + zy * zy);                                      // :96
-            }
-            sums[1] += r1 - 0.5 * (bb * bb);                                        // :87
-            maxs[0] = fmax(maxs[0], con);
-        } else {
-            const double gi = b[e];
-            if (MODE == 0) {
-                const double d = ut[0] - gi;                                        // SAD_denoise.m:46-52
-                un[0] = (d > lam * tau) ? ut[0] - lam * tau : ((d < (-1.0) * lam * tau) ? ut[0] + lam * tau : gi);
-            }
-            if (MODE == 0 && sizeof(S) == 4) un[0] = (double)(S)un[0];
-            sums[0] += fabs(un[0] - gi);                                            // :40
-            const double z = -w[0] / lam;                                           // :60
-            sums[1] += z * gi;                                                      // :66
-            maxs[0] = fmax(maxs[0], fabs(z));                                       // :63-65
-        }
+        double un[NC], uo[NC];
+        pw_primal_point<S, MODE, GT, true>(P, xc, v, g, b, e, i, j, un, uo, sums, maxs);
         if (MODE == 0) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) xn[(size_t)c * fs + e] = (S)un[c];
@@ -193,6 +218,86 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_primal(PwParams P, const S *__r
     }
     block_reduce_store<PW_NS, PW_NM>(sums, maxs, red,
                                      part + ((size_t)prob * gridDim.x + blockIdx.x) * PW_PSTRIDE);
+}
+
+// ---- fused iteration: primal step n and dual step n+1 in one pass ------------------------------------------------
+// x_{n-1} (xo), v_n (vin) -> x_n (xn), v_{n+1} (vout). The dual step needs xbar_n = x_n + theta (x_n - x_{n-1}) at the
+// pixel and at its two forward neighbours, so the primal step is evaluated at three pixels (the neighbours' inputs
+// come from cache lines this or the adjacent workgroup streams anyway). Moves 15 instead of 23 elements per pixel:
+// reads u_{n-1}(2) v_n(4) grad T(2) b(1), writes u_n(2) v_{n+1}(4). Partials per block (PWF_PSTRIDE):
+//   [0] sum ||D u_n||  (F, primal row n)   [1] G(u_n) summand  [2] G*(-K'v_n) summand
+//   [3] max ||v_{n+1}|| (F* violation of dual row n+1)  [4] max G* violation (dual row n)
+#define PWF_NS 3
+#define PWF_NM 2
+#define PWF_PSTRIDE 6
+template <typename S, int GT>
+__global__ __launch_bounds__(CP_BLOCK) void k_pw_fused(PwParams P, const S *__restrict__ xo_, S *__restrict__ xn_,
+                                                       const S *__restrict__ vin_, S *__restrict__ vout_,
+                                                       const S *__restrict__ g_, const S *__restrict__ b_,
+                                                       const PwCtrl *__restrict__ ctrl, double *__restrict__ part) {
+    __shared__ double red[CP_WAVES * PWF_PSTRIDE];
+    constexpr int NC = (GT == GT_SAD_DEN) ? 1 : 2;
+    const int prob = blockIdx.y;
+    if (ctrl[prob].stop) return;
+    const int m = P.m, fs = P.fs;
+    const S *xo = xo_ + (size_t)prob * P.nxf * fs;
+    S *xn = xn_ + (size_t)prob * P.nxf * fs;
+    const S *vin = vin_ + (size_t)prob * P.nvf * fs;
+    S *vout = vout_ + (size_t)prob * P.nvf * fs;
+    const S *g = g_ + (size_t)prob * 2 * fs, *b = b_ + (size_t)prob * fs;
+    const double sigma = P.sigma, theta = P.theta;
+    double sums[PWF_NS] = {0.0, 0.0, 0.0}, maxs[PWF_NM] = {0.0, 0.0};
+    // workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD a contiguous range of
+    // 256-pixel chunks, so that the chunk holding a pixel's (i, j+1) neighbour -- m/256 chunks further -- is streamed
+    // by the same XCD at about the same time and the neighbour loads hit its L2
+    int bx = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+    for (int q = bx * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
+        const int j = q / m, i = q - j * m, e = q + m;
+        const bool last_i = (i == m - 1), last_j = (j == P.n - 1);
+        double unA[NC], uoA[NC], unB[NC], uoB[NC], unC[NC], uoC[NC];
+        pw_primal_point<S, 0, GT, true>(P, xo, vin, g, b, e, i, j, unA, uoA, sums + 1, maxs + 1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xn[(size_t)c * fs + e] = (S)unA[c];
+        // forward neighbours: evaluated unconditionally (the addresses are inside the allocation: next column or the
+        // halo column), unused at the last row / column
+        pw_primal_point<S, 0, GT, false>(P, xo, vin, g, b, e + 1, i + 1, j, unB, uoB, nullptr, nullptr);
+        pw_primal_point<S, 0, GT, false>(P, xo, vin, g, b, e + m, i, j + 1, unC, uoC, nullptr, nullptr);
+        double dcur[2 * NC], dbar[2 * NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double u0 = unA[c], ub0 = u0 + theta * (u0 - uoA[c]);           // chambolle_pock.m:179
+            const double ui = unB[c], ubi = ui + theta * (ui - uoB[c]);
+            const double uj = unC[c], ubj = uj + theta * (uj - uoC[c]);
+            // neumann rows: PDO/test_TV_L1_registration.m:67-70
+            dcur[2 * c] = last_i ? 0.0 : (ui - u0) * P.inv_h1;
+            dcur[2 * c + 1] = last_j ? 0.0 : (uj - u0) * P.inv_h2;
+            dbar[2 * c] = last_i ? 0.0 : (ubi - ub0) * P.inv_h1;
+            dbar[2 * c + 1] = last_j ? 0.0 : (ubj - ub0) * P.inv_h2;
+        }
+        double n2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 2 * NC; ++c) n2 += dcur[c] * dcur[c];
+        sums[0] += sqrt(n2);                                                       // TV_registration.m:38,44
+        double vn[2 * NC];
+        double nn2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 2 * NC; ++c) {
+            vn[c] = (double)vin[(size_t)c * fs + e] + sigma * dbar[c];
+            nn2 += vn[c] * vn[c];
+        }
+        const double den = fmax(sqrt(nn2), 1.0);                                   // TV_registration.m:68-69
+        nn2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 2 * NC; ++c) {
+            vn[c] = (double)(S)(vn[c] / den);          // the stored (rounded) value is the iterate
+            vout[(size_t)c * fs + e] = (S)vn[c];
+            nn2 += vn[c] * vn[c];
+        }
+        maxs[0] = fmax(maxs[0], sqrt(nn2));                                        // TV_registration.m:60-62
+    }
+    block_reduce_store<PWF_NS, PWF_NM>(sums, maxs, red,
+                                       part + ((size_t)prob * gridDim.x + blockIdx.x) * PWF_PSTRIDE);
 }
 
 struct PwFinArgs {
@@ -269,6 +374,172 @@ __global__ __launch_bounds__(PW_FIN_THREADS) void k_pw_fin(PwFinArgs A, const do
                 ok = false;
         }
         if (ok) { ctrl[prob].stop = 1; ctrl[prob].stop_iter = A.rpF; }
+    }
+}
+
+// ---- fused iteration, marching form ---------------------------------------------------------------------------------
+// Same step as k_pw_fused with one primal evaluation per pixel instead of three. A wave owns 63 rows x PW_STRIP-ish
+// columns and marches along j: at step j it evaluates the primal step at column j+1 (which becomes the pixel's own
+// value at the next step), takes the (i+1, j) neighbour from lane+1 (cross-lane shift, no LDS, no barrier) and then
+// does the dual step at (i, j). Lane 63 is a halo lane (its row belongs to the next wave: evaluated, never stored);
+// the evaluation of the column after the strip is the only other redundancy: (64/63) * (C+1)/C evaluations per pixel.
+// Partials as k_pw_fused, one row per workgroup of 4 independent waves.
+template <typename S, int GT>
+__global__ __launch_bounds__(CP_BLOCK) void k_pw_march(PwParams P, int strip, int ngroups, int nwaves,
+                                                       const S *__restrict__ xo_, S *__restrict__ xn_,
+                                                       const S *__restrict__ vin_, S *__restrict__ vout_,
+                                                       const S *__restrict__ g_, const S *__restrict__ b_,
+                                                       const PwCtrl *__restrict__ ctrl, double *__restrict__ part) {
+    __shared__ double red[CP_WAVES * PWF_PSTRIDE];
+    constexpr int NC = (GT == GT_SAD_DEN) ? 1 : 2;
+    const int prob = blockIdx.y;
+    if (ctrl[prob].stop) return;
+    const int m = P.m, fs = P.fs;
+    const S *xo = xo_ + (size_t)prob * P.nxf * fs;
+    S *xn = xn_ + (size_t)prob * P.nxf * fs;
+    const S *vin = vin_ + (size_t)prob * P.nvf * fs;
+    S *vout = vout_ + (size_t)prob * P.nvf * fs;
+    const S *g = g_ + (size_t)prob * 2 * fs, *b = b_ + (size_t)prob * fs;
+    const double sigma = P.sigma, theta = P.theta;
+    double sums[PWF_NS] = {0.0, 0.0, 0.0}, maxs[PWF_NM] = {0.0, 0.0};
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * CP_WAVES + (threadIdx.x >> 6);       // wave index: row group fastest, then strip
+    if (w < nwaves) {
+        const int grp = w % ngroups, st = w / ngroups;
+        const int i = grp * 63 + lane;
+        const bool own = (lane < 63) && (i < m);                        // this lane stores / counts row i
+        const int ic = min(i, m - 1);                                   // rows past the end: clamped address, masked out
+        const bool last_i = (i == m - 1);
+        const int j0 = st * strip, j1 = min(j0 + strip, P.n);
+        double unA[NC], uoA[NC], vA[2 * NC];
+        {
+            double gs[2] = {0.0, 0.0}, gm[1] = {0.0};
+            const int e = (j0 + 1) * m + ic;
+            pw_primal_point<S, 0, GT, true>(P, xo, vin, g, b, e, ic, j0, unA, uoA, gs, gm, vA);
+            if (own) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) xn[(size_t)c * fs + e] = (S)unA[c];
+                sums[1] += gs[0]; sums[2] += gs[1]; maxs[1] = fmax(maxs[1], gm[0]);
+            }
+        }
+        for (int j = j0; j < j1; ++j) {
+            const int e = (j + 1) * m + ic;
+            const bool last_j = (j == P.n - 1);
+            // primal step at (i, j+1): this wave's own pixel if the column is inside the strip, else the halo column
+            double unC[NC], uoC[NC], vC[2 * NC];
+            {
+                double gs[2] = {0.0, 0.0}, gm[1] = {0.0};
+                pw_primal_point<S, 0, GT, true>(P, xo, vin, g, b, e + m, ic, j + 1, unC, uoC, gs, gm, vC);
+                if (own && j + 1 < j1) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) xn[(size_t)c * fs + e + m] = (S)unC[c];
+                    sums[1] += gs[0]; sums[2] += gs[1]; maxs[1] = fmax(maxs[1], gm[0]);
+                }
+            }
+            double dcur[2 * NC], dbar[2 * NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double u0 = unA[c], uold = uoA[c];
+                const double ui = __shfl_down(u0, 1), uiold = __shfl_down(uold, 1);    // (i+1, j) from lane+1
+                const double ub0 = u0 + theta * (u0 - uold);                           // chambolle_pock.m:179
+                const double ubi = ui + theta * (ui - uiold);
+                const double uj = unC[c], ubj = uj + theta * (uj - uoC[c]);
+                // neumann rows: PDO/test_TV_L1_registration.m:67-70
+                dcur[2 * c] = last_i ? 0.0 : (ui - u0) * P.inv_h1;
+                dcur[2 * c + 1] = last_j ? 0.0 : (uj - u0) * P.inv_h2;
+                dbar[2 * c] = last_i ? 0.0 : (ubi - ub0) * P.inv_h1;
+                dbar[2 * c + 1] = last_j ? 0.0 : (ubj - ub0) * P.inv_h2;
+            }
+            double n2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 2 * NC; ++c) n2 += dcur[c] * dcur[c];
+            double vn[2 * NC];
+            double nn2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 2 * NC; ++c) {
+                vn[c] = vA[c] + sigma * dbar[c];
+                nn2 += vn[c] * vn[c];
+            }
+            const double den = fmax(sqrt(nn2), 1.0);                                   // TV_registration.m:68-69
+            nn2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 2 * NC; ++c) {
+                vn[c] = (double)(S)(vn[c] / den);          // the stored (rounded) value is the iterate
+                nn2 += vn[c] * vn[c];
+            }
+            if (own) {
+#pragma unroll
+                for (int c = 0; c < 2 * NC; ++c) vout[(size_t)c * fs + e] = (S)vn[c];
+                sums[0] += sqrt(n2);                                                   // TV_registration.m:38,44
+                maxs[0] = fmax(maxs[0], sqrt(nn2));                                    // TV_registration.m:60-62
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { unA[c] = unC[c]; uoA[c] = uoC[c]; }
+#pragma unroll
+            for (int c = 0; c < 2 * NC; ++c) vA[c] = vC[c];
+        }
+    }
+    block_reduce_store<PWF_NS, PWF_NM>(sums, maxs, red,
+                                       part + ((size_t)prob * gridDim.x + blockIdx.x) * PWF_PSTRIDE);
+}
+
+// history rows of the fused iteration n: primal row n complete, G* part of dual row n (its F* violation was written by
+// the previous launch), F* violation of dual row n+1; then the stop rule on rows n-4..n (chambolle_pock.m:142-153)
+struct PwFusedFinArgs {
+    int nblk, gt, n, check_stop, hist_rows;
+    double tol, lambda;
+};
+__global__ __launch_bounds__(PW_FIN_THREADS) void k_pw_fin_fused(PwFusedFinArgs A, const double *__restrict__ part_,
+                                                                 PwCtrl *ctrl, double *hist_p_, double *hist_d_) {
+    __shared__ double stage[PW_FIN_THREADS], tot[8];
+    const int prob = blockIdx.x;
+    if (ctrl[prob].stop) return;
+    const int t = threadIdx.x, slot = t & 7, sub = t >> 3;
+    const double *part = part_ + (size_t)prob * A.nblk * PWF_PSTRIDE;
+    {
+        const bool live = slot < PWF_NS + PWF_NM, is_sum = slot < PWF_NS;
+        double v = 0.0;                                   // all maxima are of non-negative quantities
+        if (live)
+            for (int bI = sub; bI < A.nblk; bI += PW_FIN_THREADS / 8) {
+                const double o = part[(size_t)bI * PWF_PSTRIDE + slot];
+                v = is_sum ? v + o : fmax(v, o);
+            }
+        stage[t] = v;
+    }
+    __syncthreads();
+    if (t < 8) {
+        const bool is_sum = t < PWF_NS;
+        double v = stage[t];
+        for (int u = 1; u < PW_FIN_THREADS / 8; ++u) {
+            const double o = stage[u * 8 + t];
+            v = is_sum ? v + o : fmax(v, o);
+        }
+        tot[t] = v;
+    }
+    __syncthreads();
+    if (t != 0) return;
+    const double tvsum = tot[0], gsum = tot[1], gssum = tot[2], vmax = tot[3], gscon = tot[4];
+    double *hp = hist_p_ + ((size_t)prob * A.hist_rows + A.n) * CP_HCOLS_PW;
+    double *hd = hist_d_ + ((size_t)prob * A.hist_rows + A.n) * CP_HCOLS_PW;
+    hp[2] = (A.gt == GT_SSD_REG) ? 0.5 * A.lambda * gsum : A.lambda * gsum;
+    hp[3] = 0.0; hp[4] = 0.0;
+    hp[1] = tvsum;
+    hp[0] = hp[2] + hp[1];                                                         // chambolle_pock.m:170-171
+    hd[1] = 0.0;
+    hd[2] = A.lambda * gssum;
+    hd[4] = (A.gt == GT_SAD_DEN) ? ((gscon > 1.0) ? gscon - 1.0 : 0.0) : gscon;
+    hd[0] = -(hd[2] + hd[1]);                                                      // chambolle_pock.m:175-176
+    hd[CP_HCOLS_PW + 3] = (vmax > 1.0) ? vmax - 1.0 : 0.0;                         // row n+1, TV_registration.m:60-62
+    if (A.check_stop && A.n >= 4) {
+        bool ok = true;
+        for (int r = A.n - 4; r <= A.n; ++r) {
+            const double *p_ = hist_p_ + ((size_t)prob * A.hist_rows + r) * CP_HCOLS_PW;
+            const double *d_ = hist_d_ + ((size_t)prob * A.hist_rows + r) * CP_HCOLS_PW;
+            const double gap = fabs((p_[0] - d_[0]) / d_[0]);
+            if (!(gap <= A.tol) || !(p_[3] <= A.tol) || !(p_[4] <= A.tol) || !(d_[3] <= A.tol) || !(d_[4] <= A.tol))
+                ok = false;
+        }
+        if (ok) { ctrl[prob].stop = 1; ctrl[prob].stop_iter = A.n; }
     }
 }
 

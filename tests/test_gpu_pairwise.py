@@ -172,3 +172,53 @@ def test_batch_matches_single():
         e1.close()
         assert np.array_equal(x1, xb[p])                      # bitwise: same kernels, same reduction order
         assert np.array_equal(h1[0], hb[0][p]) and np.array_equal(h1[1], hb[1][p])
+
+
+@pytest.mark.parametrize("model,m,n,batch,strip", [("TV_L2", 70, 55, 1, 16), ("TV_L1", 64, 33, 3, 4), ("TV_L2", 130, 20, 2, 7),
+                                                   ("DEN", 63, 17, 1, 16), ("TV_L1", 5, 3, 2, 1), ("DEN", 127, 40, 2, 3)])
+def test_marching_kernel_matches_chunk_kernel_and_split_passes(model, m, n, batch, strip, monkeypatch):
+    """The three implementations of one iteration (split passes, k_pw_fused, k_pw_march with a given strip width) on
+    shapes that are not multiples of the 63-row groups / the strip: same iterates and histories, same stop iteration."""
+    from ma_amd import engine as E, synth
+    from ma_amd.drivers import normalize
+    rng = np.random.default_rng(7)
+    fr = synth.dynamic_test_image(m, n, 2).numpy() if m >= 16 else rng.random((2, m, n))   # tiny frames are constant
+    R, T = normalize(fr[0]), normalize(fr[1])
+    mid = {"TV_L2": E.MODEL_TV_L2_REG, "TV_L1": E.MODEL_TV_L1_REG, "DEN": E.MODEL_TV_L1_DENOISE}[model]
+    nc = 1 if model == "DEN" else 2
+    lam, tau = {"TV_L2": (50.0, 4.0), "TV_L1": (4.0, 1.5), "DEN": (1.5, 0.02)}[model]
+    sigma = (1 - 1e-4) / (8 * tau)
+    Ts = np.concatenate([np.roll(T, s, axis=0).reshape(-1, order="F") for s in range(batch)])
+    Rs = np.tile(R.reshape(-1, order="F"), batch)
+    x0 = 0.3 * rng.standard_normal(nc * m * n * batch)
+    y0 = 0.2 * rng.standard_normal(2 * nc * m * n * batch)
+    out = {}
+    for tag, env in (("split", {"CP_TUNE_PW_SPLIT": "1"}), ("chunk", {"CP_TUNE_PW_STRIP": "0"}),
+                     ("march", {"CP_TUNE_PW_STRIP": str(strip)})):
+        monkeypatch.delenv("CP_TUNE_PW_SPLIT", raising=False)
+        monkeypatch.delenv("CP_TUNE_PW_STRIP", raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        eng = E.Engine(mid, m, n, lam=lam, batch=batch)
+        if model == "DEN":
+            eng.set_images(np.clip(Ts + 0.1, 0, 1))
+        else:
+            eng.set_images(Ts, Rs)
+        eng.set_primal(x0)
+        if model != "DEN":
+            eng.linearize()
+        eng.set_dual(y0)
+        eng.solve(1.0, tau, sigma, 37, 1e-2)
+        its = [eng.result(p).iterations for p in range(batch)]
+        ph, dh = eng.history()
+        out[tag] = (eng.primal(), eng.dual(), ph if batch > 1 else [ph], dh if batch > 1 else [dh], its)
+        eng.close()
+    ref = out["split"]
+    for tag in ("chunk", "march"):
+        x, y, ph, dh, its = out[tag]
+        assert its == ref[4] and np.isfinite(ref[0]).all() and np.linalg.norm(ref[0]) > 0
+        assert np.linalg.norm(x - ref[0]) <= 1e-13 * np.linalg.norm(ref[0])
+        assert np.linalg.norm(y - ref[1]) <= 1e-13 * np.linalg.norm(ref[1])
+        for p in range(batch):
+            np.testing.assert_allclose(ph[p], ref[2][p], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(dh[p], ref[3][p], rtol=1e-12, atol=1e-12)
