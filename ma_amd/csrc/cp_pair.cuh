@@ -74,11 +74,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_dual(PwParams P, const S *__res
         }
         double nrm = sqrt(nn2);
         if (MODE == 0) {
-            const double den = fmax(nrm, 1.0);                                     // TV_registration.m:68-69
+            const double iden = 1.0 / fmax(nrm, 1.0);                              // TV_registration.m:68-69
             nn2 = 0.0;
 #pragma unroll
             for (int c = 0; c < 2 * NC; ++c) {
-                vn[c] = (double)(S)(vn[c] / den);          // the stored (rounded) value is the iterate
+                vn[c] = (double)(S)(vn[c] * iden);         // the stored (rounded) value is the iterate
                 vout[(size_t)c * fs + e] = (S)vn[c];
                 nn2 += vn[c] * vn[c];
             }
@@ -95,51 +95,76 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_dual(PwParams P, const S *__res
 //   MON: gs[0] += G(un) summand, gs[1] += G*(-K'v) summand, gm[0] = max(G* violation).
 // uo receives u (the iterate before the step). Shared by k_pw_primal and by k_pw_fused, which also evaluates it at the
 // two forward neighbours of a pixel -- same code, same inputs, so the recomputed values equal the stored ones.
-template <typename S, int MODE, int GT, bool MON>
-__device__ __forceinline__ void pw_primal_point(const PwParams &P, const S *__restrict__ xc, const S *__restrict__ v,
-                                                const S *__restrict__ g, const S *__restrict__ b, int e, int i, int j,
-                                                double *un, double *uo, double *gs, double *gm, double *vc = nullptr) {
+// the values one evaluation reads; loading them is split from the arithmetic so that k_pw_march can issue the loads of
+// the next column before it works on the current one
+template <int NC>
+struct PwIn {
+    double fx0[NC], fxm[NC], fy0[NC], fym[NC], u[NC], gx, gy, bb;
+};
+// all loads unconditional: (i-1, j) at i = 0 is the previous column's last element, (i, j-1) at j = 0 the halo column
+template <typename S, int GT>
+__device__ __forceinline__ void pw_load_point(const PwParams &P, const S *__restrict__ xc, const S *__restrict__ v,
+                                              const S *__restrict__ g, const S *__restrict__ b, int e,
+                                              PwIn<(GT == GT_SAD_DEN) ? 1 : 2> &in) {
     constexpr int NC = (GT == GT_SAD_DEN) ? 1 : 2;
     const int m = P.m, fs = P.fs;
-    const double tau = P.tau, lam = P.lambda, lt = P.lambda * P.tau;
-    double w[NC], ut[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const S *fx = v + (size_t)(2 * c) * fs + e, *fy = v + (size_t)(2 * c + 1) * fs + e;
-        const double fx0 = fx[0], fy0 = fy[0];
+        in.fx0[c] = fx[0]; in.fxm[c] = fx[-1];
+        in.fy0[c] = fy[0]; in.fym[c] = fy[-m];
+        in.u[c] = xc[(size_t)c * fs + e];
+    }
+    in.gx = in.gy = 0.0;
+    if (GT != GT_SAD_DEN) { in.gx = g[e]; in.gy = g[(size_t)fs + e]; }
+    in.bb = b[e];
+}
+template <typename S, int MODE, int GT, bool MON>
+__device__ __forceinline__ void pw_eval_point(const PwParams &P, const PwIn<(GT == GT_SAD_DEN) ? 1 : 2> &in, int i, int j,
+                                              double *un, double *uo, double *gs, double *gm, double *vc = nullptr) {
+    constexpr int NC = (GT == GT_SAD_DEN) ? 1 : 2;
+    const int m = P.m;
+    // one reciprocal per quantity instead of a division per use (the passes are bound by fp64 issue slots once fused;
+    // a product with the reciprocal differs from the quotient by at most one more ulp)
+    const double tau = P.tau, lam = P.lambda, lt = P.lambda * P.tau, ilam = 1.0 / P.lambda;
+    double w[NC], ut[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double fx0 = in.fx0[c], fy0 = in.fy0[c];
         if (vc) { vc[2 * c] = fx0; vc[2 * c + 1] = fy0; }                       // v at the pixel, for the caller's dual step
-        const double ax = fwd_diff_adj(fx0, (i >= 1) ? fx[-1] : 0.0, 0.0, i, m, false, P.inv_h1);
-        const double ay = fwd_diff_adj(fy0, (j >= 1) ? fy[-m] : 0.0, 0.0, j, P.n, false, P.inv_h2);
+        const double ax = fwd_diff_adj(fx0, (i >= 1) ? in.fxm[c] : 0.0, 0.0, i, m, false, P.inv_h1);
+        const double ay = fwd_diff_adj(fy0, (j >= 1) ? in.fym[c] : 0.0, 0.0, j, P.n, false, P.inv_h2);
         w[c] = ax + ay;                                                         // (K'v)_c
-        const double u0 = xc[(size_t)c * fs + e];
+        const double u0 = in.u[c];
         ut[c] = u0 - tau * w[c];                                                // chambolle_pock.m:165
         un[c] = u0;
         uo[c] = u0;
     }
     if (GT == GT_SAD_REG) {
-        const double gx = g[e], gy = g[(size_t)fs + e], bb = b[e];
+        const double gx = in.gx, gy = in.gy, bb = in.bb;
         const double ngs = gx * gx + gy * gy;
+        const double ings = 1.0 / ngs;                                          // only used where ngs > 1e-14
         if (MODE == 0) {
             const double phi = bb + (gx * ut[0] + gy * ut[NC - 1]);             // SAD_registration.m:46
             if (phi < (-tau) * lam * ngs) { un[0] = ut[0] + tau * lam * gx; un[NC - 1] = ut[NC - 1] + tau * lam * gy; }
             else if (phi > tau * lam * ngs) { un[0] = ut[0] - tau * lam * gx; un[NC - 1] = ut[NC - 1] - tau * lam * gy; }
-            else if (ngs > 1e-14) { const double r = phi / ngs; un[0] = ut[0] - gx * r; un[NC - 1] = ut[NC - 1] - gy * r; }
+            else if (ngs > 1e-14) { const double r = phi * ings; un[0] = ut[0] - gx * r; un[NC - 1] = ut[NC - 1] - gy * r; }
             else { un[0] = ut[0]; un[NC - 1] = ut[NC - 1]; }                    // :58-76
         }
         if (MODE == 0 && sizeof(S) == 4) { un[0] = (double)(S)un[0]; un[NC - 1] = (double)(S)un[NC - 1]; }
         if (MON) {
             gs[0] += fabs(bb + (gx * un[0] + gy * un[NC - 1]));                 // :47
             // conjugate at -K'v, scaled by 1/lambda  (:86-138)
-            const double zx = -w[0] / lam, zy = -w[NC - 1] / lam;
+            const double zx = -w[0] * ilam, zy = -w[NC - 1] * ilam;
             double val, con;
             if (ngs < 1e-14) {
                 val = -fabs(bb);
                 con = sqrt(zx * zx + zy * zy);
             } else {
-                const double f = -bb / ngs;
+                const double f = -bb * ings;
                 val = zx * (f * gx) + zy * (f * gy);
-                const double ng = sqrt(ngs);
-                const double r0 = (gx * zx + gy * zy) / ng, r1 = (-gy * zx + gx * zy) / ng;
+                const double ng = sqrt(ngs), ing = ng * ings;
+                const double r0 = (gx * zx + gy * zy) * ing, r1 = (-gy * zx + gx * zy) * ing;
                 if (r0 > ng) con = (zx - gx) * (zx - gx) + (zy - gy) * (zy - gy);   // squared (:126)
                 else if (r0 < -ng) con = (zx + gx) * (zx + gx) + (zy + gy) * (zy + gy);   // squared (:130)
                 else con = fabs(r1);                                            // plain (:134)
@@ -148,28 +173,28 @@ __device__ __forceinline__ void pw_primal_point(const PwParams &P, const S *__re
             gm[0] = fmax(gm[0], con);
         }
     } else if (GT == GT_SSD_REG) {
-        const double gx = g[e], gy = g[(size_t)fs + e], bb = b[e];
+        const double gx = in.gx, gy = in.gy, bb = in.bb;
         const double ngs = gx * gx + gy * gy;
         if (MODE == 0) {
             // (I + lt*g g') r = ut - lt*g*b     SSD_registration.m:56-63 (2x2 block solve)
             const double cx = ut[0] - lt * gx * bb, cy = ut[NC - 1] - lt * gy * bb;
             const double a11 = 1.0 + lt * gx * gx, a12 = lt * gx * gy, a22 = 1.0 + lt * gy * gy;
-            const double det = a11 * a22 - a12 * a12;
-            un[0] = (a22 * cx - a12 * cy) / det;
-            un[NC - 1] = (a11 * cy - a12 * cx) / det;
+            const double idet = 1.0 / (a11 * a22 - a12 * a12);
+            un[0] = (a22 * cx - a12 * cy) * idet;
+            un[NC - 1] = (a11 * cy - a12 * cx) * idet;
         }
         if (MODE == 0 && sizeof(S) == 4) { un[0] = (double)(S)un[0]; un[NC - 1] = (double)(S)un[NC - 1]; }
         if (MON) {
             const double res = (gx * un[0] + gy * un[NC - 1]) + bb;
             gs[0] += res * res;                                                 // :50-51
-            const double zx = -w[0] / lam, zy = -w[NC - 1] / lam;               // :70
+            const double zx = -w[0] * ilam, zy = -w[NC - 1] * ilam;             // :70
             const double dd = (zx - bb * gx) * gx + (zy - bb * gy) * gy;
             double r1 = 0.5 * (dd * dd);                                        // :84
             double con;
             if (ngs > 1e-7) {                                                   // :81
-                r1 = r1 / (ngs * ngs);
-                const double ng = sqrt(ngs);
-                con = fabs((-gy / ng) * zx + (gx / ng) * zy);                   // :100-102
+                const double ings = 1.0 / ngs, ing = sqrt(ngs) * ings;
+                r1 = r1 * (ings * ings);
+                con = fabs((-gy * ing) * zx + (gx * ing) * zy);                 // :100-102
             } else {
                 con = sqrt(zx * zx + zy * zy);                                  // :96
             }
@@ -177,7 +202,7 @@ __device__ __forceinline__ void pw_primal_point(const PwParams &P, const S *__re
             gm[0] = fmax(gm[0], con);
         }
     } else {
-        const double gi = b[e];
+        const double gi = in.bb;
         if (MODE == 0) {
             const double d = ut[0] - gi;                                        // SAD_denoise.m:46-52
             un[0] = (d > lam * tau) ? ut[0] - lam * tau : ((d < (-1.0) * lam * tau) ? ut[0] + lam * tau : gi);
@@ -185,11 +210,20 @@ __device__ __forceinline__ void pw_primal_point(const PwParams &P, const S *__re
         if (MODE == 0 && sizeof(S) == 4) un[0] = (double)(S)un[0];
         if (MON) {
             gs[0] += fabs(un[0] - gi);                                          // :40
-            const double z = -w[0] / lam;                                       // :60
+            const double z = -w[0] * ilam;                                      // :60
             gs[1] += z * gi;                                                    // :66
             gm[0] = fmax(gm[0], fabs(z));                                       // :63-65
         }
     }
+}
+
+template <typename S, int MODE, int GT, bool MON>
+__device__ __forceinline__ void pw_primal_point(const PwParams &P, const S *__restrict__ xc, const S *__restrict__ v,
+                                                const S *__restrict__ g, const S *__restrict__ b, int e, int i, int j,
+                                                double *un, double *uo, double *gs, double *gm, double *vc = nullptr) {
+    PwIn<(GT == GT_SAD_DEN) ? 1 : 2> in;
+    pw_load_point<S, GT>(P, xc, v, g, b, e, in);
+    pw_eval_point<S, MODE, GT, MON>(P, in, i, j, un, uo, gs, gm, vc);
 }
 
 template <typename S, int MODE, int GT>
@@ -286,11 +320,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_fused(PwParams P, const S *__re
             vn[c] = (double)vin[(size_t)c * fs + e] + sigma * dbar[c];
             nn2 += vn[c] * vn[c];
         }
-        const double den = fmax(sqrt(nn2), 1.0);                                   // TV_registration.m:68-69
+        const double iden = 1.0 / fmax(sqrt(nn2), 1.0);                            // TV_registration.m:68-69
         nn2 = 0.0;
 #pragma unroll
         for (int c = 0; c < 2 * NC; ++c) {
-            vn[c] = (double)(S)(vn[c] / den);          // the stored (rounded) value is the iterate
+            vn[c] = (double)(S)(vn[c] * iden);         // the stored (rounded) value is the iterate
             vout[(size_t)c * fs + e] = (S)vn[c];
             nn2 += vn[c] * vn[c];
         }
@@ -422,14 +456,19 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_march(PwParams P, int strip, in
                 sums[1] += gs[0]; sums[2] += gs[1]; maxs[1] = fmax(maxs[1], gm[0]);
             }
         }
+        PwIn<NC> nxt;
+        pw_load_point<S, GT>(P, xo, vin, g, b, (j0 + 2) * m + ic, nxt);
         for (int j = j0; j < j1; ++j) {
             const int e = (j + 1) * m + ic;
             const bool last_j = (j == P.n - 1);
-            // primal step at (i, j+1): this wave's own pixel if the column is inside the strip, else the halo column
+            // primal step at (i, j+1): this wave's own pixel if the column is inside the strip, else the halo column.
+            // Its inputs were loaded one step ago; the loads of column j+2 go out now (clamped to the halo column)
+            const PwIn<NC> cur = nxt;
+            pw_load_point<S, GT>(P, xo, vin, g, b, (min(j + 2, P.n) + 1) * m + ic, nxt);
             double unC[NC], uoC[NC], vC[2 * NC];
             {
                 double gs[2] = {0.0, 0.0}, gm[1] = {0.0};
-                pw_primal_point<S, 0, GT, true>(P, xo, vin, g, b, e + m, ic, j + 1, unC, uoC, gs, gm, vC);
+                pw_eval_point<S, 0, GT, true>(P, cur, ic, j + 1, unC, uoC, gs, gm, vC);
                 if (own && j + 1 < j1) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) xn[(size_t)c * fs + e + m] = (S)unC[c];
@@ -460,11 +499,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_march(PwParams P, int strip, in
                 vn[c] = vA[c] + sigma * dbar[c];
                 nn2 += vn[c] * vn[c];
             }
-            const double den = fmax(sqrt(nn2), 1.0);                                   // TV_registration.m:68-69
+            const double iden = 1.0 / fmax(sqrt(nn2), 1.0);                            // TV_registration.m:68-69
             nn2 = 0.0;
 #pragma unroll
             for (int c = 0; c < 2 * NC; ++c) {
-                vn[c] = (double)(S)(vn[c] / den);          // the stored (rounded) value is the iterate
+                vn[c] = (double)(S)(vn[c] * iden);         // the stored (rounded) value is the iterate
                 nn2 += vn[c] * vn[c];
             }
             if (own) {
