@@ -813,9 +813,9 @@ static const double *fused_partials(cp_engine *h, int *rows) {
     return h->part2;
 }
 
-// warm start of the eigensolves from the previous iteration's bases; a cold start every 32 iterations (and at the first
-// one) keeps the accumulated product of rotations orthogonal to rounding
-static inline int efused_warm(int n) { return (n > 1 && (n & 31) != 1) ? 1 : 0; }
+// warm start of the eigensolves from the previous iteration's bases; a cold start every 128 iterations (and at the first
+// one) keeps the accumulated product of rotations orthogonal to rounding (the drift is ~16 eps per warm iteration)
+static inline int efused_warm(int n) { return (n > 1 && (n & 127) != 1) ? 1 : 0; }
 
 // ---- fused NN-TV path: F_0 = dual step 1 alone, then one k_mf_fused_tv + k_mf_efused per iteration -------------
 static int mf_fused_start(cp_engine *h, const MfParams &P, double tol) {

@@ -274,15 +274,16 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
                                                               CpCtrl *ctrl, double *__restrict__ Wout, double *hist_p,
                                                               double *hist_d, double *__restrict__ vwarm) {
     // GG[0] = Gram(y3~), GG[1] = deflated Gram(B*L); VV: accumulated rotations; V0: warm-start bases; Tm: scratch
-    __shared__ double GG[2][16][17], VV[2][16][17], V0[2][16][17], Tm[2][16][17], G2[16][17], sc[CP_NSCAL], cs[2][8][2],
-        dvec[16], stage[CP_RED_THREADS];
+    // (Tm doubles as the second G buffer of the eigensolve, VB is its second V buffer)
+    __shared__ double GG[2][16][17], VV[2][16][17], V0[2][16][17], Tm[2][16][17], VB[2][16][17], G2[16][17], sc[CP_NSCAL],
+        dvec[16], stage[CP_RED_THREADS], stage2[CP_RED_THREADS];
     double (*G)[17] = GG[0], (*V)[17] = VV[0], (*G2h)[17] = GG[1];
-    __shared__ int pq[2][8][2], rotflag[2];
+    __shared__ double cs[2][16][2];             // rotations of the current Jacobi round, per index
+    __shared__ double Sv[16], zv[16], zs[16];   // l1-ball projection of the singular values (dynamically indexed: LDS)
     __shared__ double res[4];   // spmax, con3
     if (ctrl->stop) return;
     const int t = threadIdx.x;
-    reduce_partials(part + 256, A.nblk, G2, sc, stage);   // Gram(B*L_n)   (second Gram block)
-    reduce_partials(part, A.nblk, G, sc, stage);          // Gram(y3~_{n+1}) and the scalars
+    reduce_partials2(part, A.nblk, G, G2, sc, stage, stage2);   // Gram(y3~_{n+1}), Gram(B*L_n) and the scalars
     if (t < 256) {   // Gram(B*L_n) restricted to the complement of (1,..,1) (see k_mf_fin)
         const int a = t >> 4, bq = t & 15, K = A.K;
         double acc = 0.0;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
             GG[mid][r][c] = acc;
         }
         __syncthreads();
-        jacobi16_pair(GG, VV, cs, pq, rotflag);
+        jacobi16_pair(GG, VV, Tm, VB, cs);
         if (A.warm) {   // eigenvectors in the original basis: V0 * V
             double acc = 0.0;
             for (int i = 0; i < 16; ++i) acc += V0[mid][r][i] * VV[mid][i][c];
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
     if (t == 0) {
         const int K = A.K;
         const double nu = ctrl->nu, mu_ = nu * A.sigma;   // NNE/nuclear_norm_constraint.m:72
-        double S[16], z[16], zs[16];
+        double *S = Sv, *z = zv;
         double sumz = 0.0;
         for (int i = 0; i < K; ++i) {
             S[i] = sqrt(fmax(G[i][i], 0.0));

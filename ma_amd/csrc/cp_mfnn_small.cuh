@@ -67,6 +67,55 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
     __syncthreads();
 }
 
+// Both Gram blocks of the fused pass (Gram(y3~) at +CP_NSCAL, Gram(B*L) 256 further) and the scalars in ONE phase:
+// every load of the kernel's reduction is in flight before the first barrier (k_mf_efused is latency-bound: a single
+// workgroup, a few dependent global round trips). 2 groups x 512 Gram entries stride the rows with 8 accumulators,
+// the scalars use 32 sub-groups of 32 threads; fixed order, deterministic. stage, stage2: 1024 doubles each.
+__device__ __forceinline__ void reduce_partials2(const double *__restrict__ part, int nblk, double (*G)[17],
+                                                 double (*G2)[17], double *sc, double *stage, double *stage2) {
+    const int t = threadIdx.x;
+    {
+        const int grp = t >> 9, e = t & 511;
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = 0.0;
+        const double *src = part + CP_NSCAL + e;
+        int bI = grp;
+        for (; bI + 14 < nblk; bI += 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += src[(size_t)(bI + 2 * u) * CP_PSTRIDE];
+        }
+        for (int u = 0; bI < nblk; bI += 2, ++u) a[u & 7] += src[(size_t)bI * CP_PSTRIDE];
+        const int slot = t & 31, sub = t >> 5;   // 32 sub-groups of 32 threads (CP_NSCAL <= 32 slots used)
+        const bool is_sum = slot < CP_NSUM;
+        double v = is_sum ? 0.0 : -1.0e300;
+        if (slot < CP_NSCAL)
+            for (int bJ = sub; bJ < nblk; bJ += 32) {
+                const double o = part[(size_t)bJ * CP_PSTRIDE + slot];
+                v = is_sum ? v + o : fmax(v, o);
+            }
+        stage[t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        stage2[t] = v;
+    }
+    __syncthreads();
+    if (t < 512) {
+        const double v = stage[t] + stage[512 + t];
+        const int e = t & 255;
+        if (t < 256) G[e >> 4][e & 15] = v;
+        else G2[e >> 4][e & 15] = v;
+    } else if (t < 512 + CP_NSCAL) {
+        const int q = t - 512;
+        const bool is_sum = q < CP_NSUM;
+        double v = stage2[q];
+        for (int sub = 1; sub < 32; ++sub) {
+            const double o = stage2[sub * 32 + q];
+            v = is_sum ? v + o : fmax(v, o);
+        }
+        sc[q] = v;
+    }
+    __syncthreads();
+}
+
 // ---- parallel cyclic Jacobi on a symmetric 16 x 16 matrix in LDS (256 threads) -------------------
 // Round-robin ordering: 15 rounds of 8 disjoint rotations per sweep. On exit diag(G) holds the
 // eigenvalues and (WITH_V) the columns of V the eigenvectors: G_in = V diag V'.
@@ -133,74 +182,66 @@ __device__ void jacobi16(double (*G)[17], double (*V)[17], double (*cs)[2], int 
     }
 }
 
-// Two independent symmetric 16 x 16 eigenproblems side by side: threads 0..255 work on (G[0], V[0]), threads 256..511 on
-// (G[1], V[1]). Same rotations per matrix as jacobi16; a sweep starts only if some off-diagonal entry still exceeds the
-// rotation threshold (a sweep without rotations would be a no-op). V must be initialised by the caller (identity, or
-// anything orthogonal: the rotations are accumulated onto it). Call with exactly 512 live threads.
-__device__ void jacobi16_pair(double (*G)[16][17], double (*V)[16][17], double (*cs)[8][2], int (*pq)[8][2], int *rotflag) {
+// Two symmetric 16 x 16 eigenproblems side by side on 512 threads (matrix mid = t >> 8, one thread per entry).
+// Cyclic Jacobi with the round-robin ordering of jacobi16. A round applies its 8 disjoint rotations as ONE two-sided
+// update G' = J' G J, V' = V J per entry, read from one buffer and written to the other: two barriers per round (after
+// the 16 threads of row 0 have published the rotation of every index, after the update) instead of three, and G and V
+// move together. The rotation comes from two reciprocal square roots (c^2 = (1 + |d|/h)/2, s = sign(d) apq / (h c) with
+// d = aqq - app, h = |(d, 2 apq)|) instead of three divisions and three square roots in sequence -- that dependent
+// chain, not the barriers, bounded the previous version. G[mid], V[mid] hold the result; Gb, Vb are the second
+// buffers, cs the published rotations. A sweep starts only if an off-diagonal entry is above the threshold somewhere.
+__device__ __forceinline__ void jacobi_rot(double app, double aqq, double apq, double &c, double &s) {
+    c = 1.0; s = 0.0;
+    if (apq * apq > 1.0e-34 * fabs(app * aqq) && fabs(apq) > 1.0e-300) {
+        const double d = aqq - app;
+        double h, rh, rc;
+        sqrt_rsqrt(fma(d, d, 4.0 * apq * apq), h, rh);
+        sqrt_rsqrt(fma(0.5 * fabs(d), rh, 0.5), c, rc);
+        s = copysign(1.0, d) * apq * rh * rc;
+    }
+}
+__device__ void jacobi16_pair(double (*G)[16][17], double (*V)[16][17], double (*Gb)[16][17], double (*Vb)[16][17],
+                              double (*cs)[16][2]) {
     const int t = threadIdx.x, mid = t >> 8, tl = t & 255;
-    double (*Gm)[17] = G[mid];
-    double (*Vm)[17] = V[mid];
+    const int a = tl >> 4, b = tl & 15;
     {
-        const int r = tl >> 4, c = tl & 15;
-        const double s = 0.5 * (Gm[r][c] + Gm[c][r]);
+        const double sy = 0.5 * (G[mid][a][b] + G[mid][b][a]);
         __syncthreads();
-        Gm[r][c] = s;
+        G[mid][a][b] = sy;
     }
     __syncthreads();
+    double (*Gc)[17] = G[mid], (*Gn)[17] = Gb[mid], (*Vc)[17] = V[mid], (*Vn)[17] = Vb[mid];
     for (int sweep = 0; sweep < 30; ++sweep) {
-        if (tl == 0) rotflag[mid] = 0;
-        __syncthreads();
-        {
-            const int r = tl >> 4, c = tl & 15;
-            const double apq = Gm[r][c];
-            if (r < c && fabs(apq) > 1.0e-17 * sqrt(fabs(Gm[r][r] * Gm[c][c])) && fabs(apq) > 1.0e-300) rotflag[mid] = 1;
-        }
-        __syncthreads();
-        if (rotflag[0] == 0 && rotflag[1] == 0) break;
-        for (int r = 0; r < 15; ++r) {
-            if (tl < 8) {
-                int p, q;
-                if (tl == 0) { p = 15; q = r; }
-                else { p = (r + tl) % 15; q = (r - tl + 15) % 15; }
-                if (p > q) { const int tmp = p; p = q; q = tmp; }
-                const double app = Gm[p][p], aqq = Gm[q][q], apq = Gm[p][q];
-                double c = 1.0, s = 0.0;
-                if (fabs(apq) > 1.0e-17 * sqrt(fabs(app * aqq)) && fabs(apq) > 1.0e-300) {
-                    const double th = (aqq - app) / (2.0 * apq);
-                    const double tt = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
-                    c = 1.0 / sqrt(tt * tt + 1.0);
-                    s = tt * c;
-                }
-                cs[mid][tl][0] = c; cs[mid][tl][1] = s; pq[mid][tl][0] = p; pq[mid][tl][1] = q;
+        const double apq0 = Gc[a][b];
+        const int need = (a < b && apq0 * apq0 > 1.0e-34 * fabs(Gc[a][a] * Gc[b][b]) && fabs(apq0) > 1.0e-300) ? 1 : 0;
+        if (!__syncthreads_or(need)) break;
+        for (int rd = 0; rd < 15; ++rd) {
+            // partner of an index in round rd: (15, rd) and ((rd + k) % 15, (rd - k) % 15), k = 1..7
+            const int pa = (a == 15) ? rd : ((a == rd) ? 15 : (2 * rd - a + 15) % 15);
+            const int pb = (b == 15) ? rd : ((b == rd) ? 15 : (2 * rd - b + 15) % 15);
+            if (a == 0) {   // rotation seen from index b: new(b) = c x(b) + s x(partner), s negated for the lower index
+                const int p = min(b, pb), q = max(b, pb);
+                double c, sn;
+                jacobi_rot(Gc[p][p], Gc[q][q], Gc[p][q], c, sn);
+                cs[mid][b][0] = c;
+                cs[mid][b][1] = (b == p) ? -sn : sn;
             }
             __syncthreads();
-            {
-                const int pi = (tl >> 4) & 7, l = tl & 15;
-                const int p = pq[mid][pi][0], q = pq[mid][pi][1];
-                const double c = cs[mid][pi][0], s = cs[mid][pi][1];
-                if (tl < 128) {
-                    const double gp = Gm[l][p], gq = Gm[l][q];
-                    Gm[l][p] = c * gp - s * gq;
-                    Gm[l][q] = s * gp + c * gq;
-                } else {
-                    const double vp = Vm[l][p], vq = Vm[l][q];
-                    Vm[l][p] = c * vp - s * vq;
-                    Vm[l][q] = s * vp + c * vq;
-                }
-            }
+            const double ca = cs[mid][a][0], sa = cs[mid][a][1], cb = cs[mid][b][0], sb = cs[mid][b][1];
+            const double t_ab = cb * Gc[a][b] + sb * Gc[a][pb];       // column transform, rows a and partner(a)
+            const double t_pb = cb * Gc[pa][b] + sb * Gc[pa][pb];
+            Gn[a][b] = ca * t_ab + sa * t_pb;                         // row transform
+            Vn[a][b] = cb * Vc[a][b] + sb * Vc[a][pb];
             __syncthreads();
-            if (tl < 128) {
-                const int pi = tl >> 4, l = tl & 15;
-                const int p = pq[mid][pi][0], q = pq[mid][pi][1];
-                const double c = cs[mid][pi][0], s = cs[mid][pi][1];
-                const double gp = Gm[p][l], gq = Gm[q][l];
-                Gm[p][l] = c * gp - s * gq;
-                Gm[q][l] = s * gp + c * gq;
-            }
-            __syncthreads();
+            { double (*tmp)[17] = Gc; Gc = Gn; Gn = tmp; }
+            { double (*tmp)[17] = Vc; Vc = Vn; Vn = tmp; }
         }
     }
+    if (Gc != G[mid]) {     // an odd number of rounds in total (uniform: both matrices march together): copy back
+        G[mid][a][b] = Gc[a][b];
+        V[mid][a][b] = Vc[a][b];
+    }
+    __syncthreads();
 }
 
 // ---- dual-side finalisation: W for y3, F* values, primal row rp, stop rule ------------------------

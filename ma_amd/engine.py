@@ -125,6 +125,26 @@ def _f64(a):
     return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
 
 
+_torch_checked = False
+
+
+def _torch_first():
+    """If PyTorch-ROCm is loaded in this process, let it initialise its device before the engine's first HIP call: the
+    torch wheel bundles its own HIP runtime, and it only finds the GPUs when it comes first."""
+    global _torch_checked
+    if _torch_checked:
+        return
+    _torch_checked = True
+    import sys
+    t = sys.modules.get("torch")
+    if t is not None:
+        try:
+            if t.cuda.is_available():
+                t.cuda.init()
+        except Exception:
+            pass
+
+
 class Engine:
     """One handle = one (F, G, K) triple of the reference at one resolution."""
 
@@ -160,6 +180,7 @@ class Engine:
             self.ny = 2 * nc * m * n * batch
             self.cols = 5
         self._h = C.c_void_p()
+        _torch_first()
         _chk(lib.cp_create(C.byref(d), C.byref(self._h)))
 
     def close(self):

@@ -15,3 +15,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_runtime_first():
+    """The PyTorch wheel bundles its own HIP runtime; libcpengine.so links the system one. Both coexist in one process
+    only if torch initialises its device first (the other order makes torch report "No HIP GPUs are available"), so do
+    that once per session, whatever order the tests run in. A no-op without a GPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
