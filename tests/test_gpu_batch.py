@@ -17,3 +17,20 @@ def test_batch_shards_match_single_handle(world, P, fp32):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0 and "batch shards == single handle" in r.stdout
+
+
+def test_bench_batch_workload_two_ranks():
+    """bench.py --workload batch with 2 ranks (gloo on one GPU): one JSON line from rank 0, all problems counted"""
+    import json
+    env = dict(os.environ, CP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29447", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "batch", "--size", "96",
+           "--problems", "9", "--steps", "6", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=250)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["unit"] == "problem-iterations/s" and out["value"] > 0
+    assert "roofline" in out and out["roofline"]["bound"] == "hbm"
