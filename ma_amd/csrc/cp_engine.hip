@@ -78,6 +78,8 @@ struct cp_engine {
     int nblk = 0;
     int pw_strip = 0;        // columns per wave of k_pw_march (0: k_pw_fused), pw_groups row groups of 63, pw_waves waves
     int pw_groups = 0, pw_waves = 0, pw_grid = 0;
+    bool time_all = false;   // CP_TUNE_TIME_ALL=1: HIP events around the small kernels of the fused paths too (each pair of
+                             // events costs a few microseconds of stream time; by default only the dominant kernel is timed)
     bool pw_split = false;   // tuning aid (CP_TUNE_PW_SPLIT=1): pairwise models on the split passes instead of k_pw_fused
     int fused_tw = 1;    // image columns per workgroup tile of k_mf_fused_tv
     int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU resident: two LDS tiles per wave)
@@ -326,6 +328,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (const char *ev = getenv("CP_TUNE_FUSED_TW")) h->fused_tw = (atoi(ev) == 4) ? 4 : (atoi(ev) == 2 ? 2 : 1);   // tuning knobs
         h->nblk_fused = std::max(1, std::min(fused_tiles(h->m, h->nl, h->fused_tw), CP_FUSED_MAXGRID));
         if (const char *ev = getenv("CP_TUNE_PW_SPLIT")) h->pw_split = atoi(ev) != 0;
+        if (const char *ev = getenv("CP_TUNE_TIME_ALL")) h->time_all = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_FUSED_GRID")) h->nblk_fused = std::max(1, std::min(h->nblk_fused, atoi(ev)));
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
@@ -837,11 +840,11 @@ static int mf_fused_iterations(cp_engine *h, const MfParams &P, int n0, int coun
         A.K = h->K; A.n = n; A.check_stop = check; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
         A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot;
         A.warm = efused_warm(n);
-        CPCHK(timer_begin(h, T_EIG));
+        if (h->time_all) CPCHK(timer_begin(h, T_EIG));
         const double *rows = fused_partials(h, &A.nblk);
         hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, rows, ctrl, h->W[nxt], h->hist_p,
                            h->hist_d, h->vwarm);
-        CPCHK(timer_end(h, T_EIG));
+        if (h->time_all) CPCHK(timer_end(h, T_EIG));
     }
     HIPCHK(hipGetLastError());
     return CP_OK;
@@ -1146,10 +1149,10 @@ static int pw_fused_iterations(cp_engine *h, const PwParams &P, int n0, int coun
         A.nblk = h->pw_strip > 0 ? h->pw_grid : h->nblk;
         A.gt = h->gt; A.n = n; A.check_stop = check; A.hist_rows = h->hist_rows; A.tol = tol;
         A.lambda = h->d.lambda;
-        CPCHK(timer_begin(h, T_FIN));
+        if (h->time_all) CPCHK(timer_begin(h, T_FIN));
         hipLaunchKernelGGL(k_pw_fin_fused, dim3(h->batch), dim3(PW_FIN_THREADS), 0, h->stream, A, h->part, ctrl, h->hist_p,
                            h->hist_d);
-        CPCHK(timer_end(h, T_FIN));
+        if (h->time_all) CPCHK(timer_end(h, T_FIN));
     }
     HIPCHK(hipGetLastError());
     return CP_OK;
@@ -1591,10 +1594,10 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             A.nblk = world; A.K = h->K; A.n = n; A.check_stop = check_stop; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
             A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot;
             A.warm = efused_warm(n);
-            CPCHK(timer_begin(h, T_EIG));
+            if (h->time_all) CPCHK(timer_begin(h, T_EIG));
             hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->W[(n + 1) & 1],
                                h->hist_p, h->hist_d, h->vwarm);
-            CPCHK(timer_end(h, T_EIG));
+            if (h->time_all) CPCHK(timer_end(h, T_EIG));
             break;
         }
         case CP_STAGE_SPLIT_DUAL: {
