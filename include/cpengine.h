@@ -218,6 +218,13 @@ int64_t cp_mg_halo_len(cp_handle h, int sel);              /* doubles per packed
 int cp_mg_halo_pack(cp_handle h, int buf, int sel, int column, double *dev_out);
 /* side = 0: left halo column, 1: right halo column <- dev_in                                           */
 int cp_mg_halo_unpack(cp_handle h, int buf, int sel, int side, const double *dev_in);
+/* the whole per-iteration halo of the fused NN-TV path in one launch: pack [u of xbuf | y1,y2 of pbuf] of the first
+ * owned column into dev_to_left (7*k*m doubles) and the Dy parts of y2 of the last owned column into dev_to_right
+ * (2*k*m doubles); unpack a right neighbour's dev_to_left / a left neighbour's dev_to_right into the halo columns.
+ * NULL skips a side (ends of the chain). Same layout as CP_SEL_X_U + CP_SEL_P_Y12 / CP_SEL_P_DY back to back.
+ * (No counterpart in the reference: its matrices are never partitioned.)                                   */
+int cp_mg_state_pack(cp_handle h, int xbuf, int pbuf, double *dev_to_left, double *dev_to_right);
+int cp_mg_state_unpack(cp_handle h, int xbuf, int pbuf, const double *dev_from_right, const double *dev_from_left);
 int cp_mg_begin(cp_handle h, double theta, double tau, double sigma);
 /* dev_buf: stage output (own reduced partials) or input (world gathered partial vectors)               */
 int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, int32_t world, double scale,

@@ -1452,10 +1452,9 @@ extern "C" int cp_kernel_time_ms(cp_handle h, const char *pass, double *ms, int6
 // row-slab multi-GPU hooks
 __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_reduce_local(int nblk, const double *__restrict__ part,
                                                                     double *__restrict__ out) {
-    __shared__ double G[16][17], G2[16][17], sc[CP_NSCAL], stage[CP_RED_THREADS];
+    __shared__ double G[16][17], G2[16][17], sc[CP_NSCAL], stage[CP_RED_THREADS], stage2[CP_RED_THREADS];
     const int t = threadIdx.x;
-    reduce_partials(part + 256, nblk, G2, sc, stage);
-    reduce_partials(part, nblk, G, sc, stage);
+    reduce_partials2(part, nblk, G, G2, sc, stage, stage2);
     if (t < CP_NSCAL) out[t] = sc[t];
     if (t < 256) {
         out[CP_NSCAL + t] = G[t >> 4][t & 15];
@@ -1473,6 +1472,32 @@ __global__ __launch_bounds__(CP_BLOCK) void k_halo_copy(int m, int fs, int nsel,
         if (sel == CP_SEL_P_Y2) f = K + s;                                 // all y2 fields
         double *p = buf + (size_t)f * fs + (size_t)col * m + i;
         if (pack) lin[gid] = *p; else *p = lin[gid];
+    }
+}
+
+// The per-iteration halo traffic of the fused NN-TV path in one launch per direction of data flow:
+//   pack:   to_left  = [u of xbuf | y1, y2 of pbuf] of the first owned column (7K fields), to_right = Dy parts of y2 of the
+//           last owned column (2K fields);
+//   unpack: from_right (a neighbour's to_left) -> halo column nl+1, from_left (a neighbour's to_right) -> halo column 0.
+// A null buffer skips that side (ends of the chain).
+__global__ __launch_bounds__(CP_BLOCK) void k_halo_state(int m, int fs, int K, int nl, int pack, double *__restrict__ xbuf,
+                                                         double *__restrict__ pbuf, double *__restrict__ a7,
+                                                         double *__restrict__ a2) {
+    const int n7 = a7 ? 7 * K * m : 0, n2 = a2 ? 2 * K * m : 0;
+    const int col7 = pack ? 1 : nl + 1, col2 = pack ? nl : 0;
+    for (int gid = blockIdx.x * CP_BLOCK + threadIdx.x; gid < n7 + n2; gid += gridDim.x * CP_BLOCK) {
+        double *p, *q;
+        if (gid < n7) {
+            const int s = gid / m, i = gid - s * m;
+            p = (s < 2 * K ? xbuf + (size_t)s * fs : pbuf + (size_t)(s - 2 * K) * fs) + (size_t)col7 * m + i;
+            q = a7 + gid;
+        } else {
+            const int g2 = gid - n7, s = g2 / m, i = g2 - s * m;
+            const int f = K + 4 * (s >> 1) + 1 + 2 * (s & 1);          // Dy u_x, Dy u_y of image s/2
+            p = pbuf + (size_t)f * fs + (size_t)col2 * m + i;
+            q = a2 + g2;
+        }
+        if (pack) *q = *p; else *p = *q;
     }
 }
 
@@ -1541,6 +1566,27 @@ extern "C" int cp_mg_halo_pack(cp_handle h, int buf, int sel, int column, double
 }
 extern "C" int cp_mg_halo_unpack(cp_handle h, int buf, int sel, int side, const double *dev_in) {
     return mg_halo(h, buf, sel, side ? (h ? h->nl + 1 : 0) : 0, 0, (double *)dev_in);   // halo columns 0 and nl+1
+}
+
+static int mg_state(cp_handle h, int xbuf, int pbuf, int pack, double *a7, double *a2) {
+    if (!h || !h->mf || h->var || h->reg != 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg the state halo needs an NN-TV handle");
+    if (h->fp32) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported halo exchange in fp32 mode");
+    HIPCHK(hipSetDevice(h->d.device));
+    double *xb = mg_buf(h, xbuf), *pb = mg_buf(h, pbuf);
+    const bool xok = (xbuf == CP_BUF_X0 || xbuf == CP_BUF_X1), pok = (pbuf == CP_BUF_P0 || pbuf == CP_BUF_P1);
+    if (!xb || !pb || !xok || !pok) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg state halo buffers %d / %d", xbuf, pbuf);
+    if (!a7 && !a2) return CP_OK;
+    const int tot = ((a7 ? 7 : 0) + (a2 ? 2 : 0)) * h->K * h->m;
+    const int grid = std::max(1, std::min((tot + CP_BLOCK - 1) / CP_BLOCK, 1024));
+    hipLaunchKernelGGL(k_halo_state, dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->fs, h->K, h->nl, pack, xb, pb, a7, a2);
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+extern "C" int cp_mg_state_pack(cp_handle h, int xbuf, int pbuf, double *dev_to_left, double *dev_to_right) {
+    return mg_state(h, xbuf, pbuf, 1, dev_to_left, dev_to_right);
+}
+extern "C" int cp_mg_state_unpack(cp_handle h, int xbuf, int pbuf, const double *dev_from_right, const double *dev_from_left) {
+    return mg_state(h, xbuf, pbuf, 0, (double *)dev_from_right, (double *)dev_from_left);
 }
 
 extern "C" int cp_mg_begin(cp_handle h, double theta, double tau, double sigma) {

@@ -78,6 +78,8 @@ def _load():
         "cp_set_stream": [vp, vp],
         "cp_mg_halo_pack": [vp, C.c_int, C.c_int, C.c_int, vp],
         "cp_mg_halo_unpack": [vp, C.c_int, C.c_int, C.c_int, vp],
+        "cp_mg_state_pack": [vp, C.c_int, C.c_int, vp, vp],
+        "cp_mg_state_unpack": [vp, C.c_int, C.c_int, vp, vp],
         "cp_mg_begin": [vp, C.c_double, C.c_double, C.c_double],
         "cp_mg_stage": [vp, C.c_int, C.c_int32, vp, C.c_int32, C.c_double, C.c_int32, C.c_double],
         "cp_mg_end": [vp, C.c_int32],
@@ -102,7 +104,7 @@ EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_im
             "cp_get_result", "cp_get_history", "cp_get_primal", "cp_get_dual", "cp_get_images", "cp_prolong",
             "cp_downsample", "cp_iterate", "cp_iterate_begin", "cp_iterate_steps", "cp_iterate_end", "cp_sync",
             "cp_kernel_time_ms", "cp_set_stream", "cp_mg_partial_len",
-            "cp_mg_halo_len", "cp_mg_halo_pack", "cp_mg_halo_unpack", "cp_mg_begin", "cp_mg_stage", "cp_mg_end",
+            "cp_mg_halo_len", "cp_mg_halo_pack", "cp_mg_halo_unpack", "cp_mg_state_pack", "cp_mg_state_unpack", "cp_mg_begin", "cp_mg_stage", "cp_mg_end",
             "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start"]
 
 BUF_X0, BUF_X1, BUF_P0, BUF_P1, BUF_XTMP = 0, 1, 2, 3, 4
@@ -316,6 +318,13 @@ class Engine:
 
     def halo_unpack(self, buf, sel, side, dev_ptr):
         _chk(lib.cp_mg_halo_unpack(self._h, buf, sel, side, C.c_void_p(dev_ptr)))
+
+    def state_pack(self, xbuf, pbuf, to_left_ptr, to_right_ptr):
+        """device pointers (0 = skip that side)"""
+        _chk(lib.cp_mg_state_pack(self._h, xbuf, pbuf, C.c_void_p(to_left_ptr or None), C.c_void_p(to_right_ptr or None)))
+
+    def state_unpack(self, xbuf, pbuf, from_right_ptr, from_left_ptr):
+        _chk(lib.cp_mg_state_unpack(self._h, xbuf, pbuf, C.c_void_p(from_right_ptr or None), C.c_void_p(from_left_ptr or None)))
 
     def mg_begin(self, theta, tau, sigma):
         _chk(lib.cp_mg_begin(self._h, theta, tau, sigma))

@@ -161,12 +161,9 @@ class MultiGpuEngine:
     def exchange_state_pack(self, xbuf, pbuf):
         """one message per neighbour and iteration: [u of x_n | y1, y2 of y_{n+1}] of the first owned column goes left,
         the Dy components of y2 of the last owned column go right"""
-        c, eng = self.comm, self.eng
-        if c.left is not None:
-            eng.halo_pack(xbuf, E.SEL_X_U, 0, self.s_left.data_ptr())
-            eng.halo_pack(pbuf, E.SEL_P_Y12, 0, self.s_left.data_ptr() + 8 * self.len_xu)
-        if c.right is not None:
-            eng.halo_pack(pbuf, E.SEL_P_DY, 1, self.s_right.data_ptr())
+        c = self.comm
+        self.eng.state_pack(xbuf, pbuf, self.s_left.data_ptr() if c.left is not None else 0,
+                            self.s_right.data_ptr() if c.right is not None else 0)
 
     def exchange_state_begin(self):
         c = self.comm
@@ -176,13 +173,10 @@ class MultiGpuEngine:
                                 from_right=self.r_right if c.right is not None else None)
 
     def exchange_state_end(self, token, xbuf, pbuf):
-        c, eng = self.comm, self.eng
+        c = self.comm
         c.exchange_end(token)
-        if c.right is not None:
-            eng.halo_unpack(xbuf, E.SEL_X_U, 1, self.r_right.data_ptr())
-            eng.halo_unpack(pbuf, E.SEL_P_Y12, 1, self.r_right.data_ptr() + 8 * self.len_xu)
-        if c.left is not None:
-            eng.halo_unpack(pbuf, E.SEL_P_DY, 0, self.r_left.data_ptr())
+        self.eng.state_unpack(xbuf, pbuf, self.r_right.data_ptr() if c.right is not None else 0,
+                              self.r_left.data_ptr() if c.left is not None else 0)
 
     # ---- engine facade ----------------------------------------------------------------------------
     def set_images(self, imgs_full):
