@@ -28,8 +28,8 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 // Reduce NS sums and NM maxima over the block; thread 0 writes them to out[0..NS+NM).
-// red: LDS scratch of at least CP_WAVES * (NS + NM) doubles.
-template <int NS, int NM>
+// red: LDS scratch of at least NWV * (NS + NM) doubles (NWV = waves of the workgroup).
+template <int NS, int NM, int NWV = CP_WAVES>
 __device__ __forceinline__ void block_reduce_store(const double (&s)[NS], const double (&mx)[NM],
                                                    double *red, double *out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -47,7 +47,7 @@ __device__ __forceinline__ void block_reduce_store(const double (&s)[NS], const 
     if (threadIdx.x < NS + NM) {
         const int a = threadIdx.x;
         double v = red[a];
-        for (int w = 1; w < CP_WAVES; ++w) {
+        for (int w = 1; w < NWV; ++w) {
             const double o = red[w * (NS + NM) + a];
             v = (a < NS) ? v + o : fmax(v, o);
         }
@@ -73,6 +73,7 @@ __device__ __forceinline__ void gram_tile_accum(const double *tile, double4_t &a
 
 // Sum the 4 waves' Gram accumulators in fixed order and write the 256 entries to out[].
 // stage: LDS scratch of CP_WAVES*256 doubles.
+template <int NWV = CP_WAVES>
 __device__ __forceinline__ void gram_block_store(const double4_t &acc, double *stage, double *out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -81,10 +82,10 @@ __device__ __forceinline__ void gram_block_store(const double4_t &acc, double *s
         stage[wave * 256 + row * 16 + col] = acc[r];
     }
     __syncthreads();
-    {
-        const int e = threadIdx.x;   // CP_BLOCK == 256 entries
+    if (threadIdx.x < 256) {
+        const int e = threadIdx.x;   // 256 entries
         double v = stage[e];
-        for (int w = 1; w < CP_WAVES; ++w) v += stage[w * 256 + e];
+        for (int w = 1; w < NWV; ++w) v += stage[w * 256 + e];
         out[e] = v;
     }
     __syncthreads();

@@ -81,6 +81,7 @@ struct cp_engine {
     bool time_all = false;   // CP_TUNE_TIME_ALL=1: HIP events around the small kernels of the fused paths too (each pair of
                              // events costs a few microseconds of stream time; by default only the dominant kernel is timed)
     bool pw_split = false;   // tuning aid (CP_TUNE_PW_SPLIT=1): pairwise models on the split passes instead of k_pw_fused
+    int fused_nt = CP_BLOCK;   // threads per workgroup of k_mf_fused_tv (512: CP_TUNE_FUSED_THREADS, with tile width 2)
     int fused_tw = 1;    // image columns per workgroup tile of k_mf_fused_tv
     int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU resident: two LDS tiles per wave)
     bool linearized = false, has_nu = false, has_images = false;
@@ -326,7 +327,8 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         // tiles turn the i+1 spill-over line of every wave into a miss of its own XCD's L2
         h->fused_tw = 1;
         if (const char *ev = getenv("CP_TUNE_FUSED_TW")) h->fused_tw = (atoi(ev) == 4) ? 4 : (atoi(ev) == 2 ? 2 : 1);   // tuning knobs
-        h->nblk_fused = std::max(1, std::min(fused_tiles(h->m, h->nl, h->fused_tw), CP_FUSED_MAXGRID));
+        if (const char *ev = getenv("CP_TUNE_FUSED_THREADS")) { if (atoi(ev) == 512) { h->fused_nt = 512; h->fused_tw = 2; } }
+        h->nblk_fused = std::max(1, std::min(fused_tiles(h->m, h->nl, h->fused_tw, h->fused_nt), CP_FUSED_MAXGRID));
         if (const char *ev = getenv("CP_TUNE_PW_SPLIT")) h->pw_split = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_TIME_ALL")) h->time_all = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_FUSED_GRID")) h->nblk_fused = std::max(1, std::min(h->nblk_fused, atoi(ev)));
@@ -762,18 +764,19 @@ static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int
 }
 
 // one launch of k_mf_fused_tv: x_{n-1} in xp, x_n written to xc; y_n in pc, y_{n+1} written to pn
-template <typename S, int TW>
+template <typename S, int TW, int NT = CP_BLOCK>
 static void launch_fused_tw(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
                             const double *W) {
     auto kern = (h->d.bc == CP_BC_LINEAR)
-                    ? (h->K == CP_KMAX ? k_mf_fused_tv<S, true, true, TW> : k_mf_fused_tv<S, true, false, TW>)
-                    : (h->K == CP_KMAX ? k_mf_fused_tv<S, false, true, TW> : k_mf_fused_tv<S, false, false, TW>);
-    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
+                    ? (h->K == CP_KMAX ? k_mf_fused_tv<S, true, true, TW, NT> : k_mf_fused_tv<S, true, false, TW, NT>)
+                    : (h->K == CP_KMAX ? k_mf_fused_tv<S, false, true, TW, NT> : k_mf_fused_tv<S, false, false, TW, NT>);
+    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(NT), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
                        (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
 }
 static void launch_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
                          const double *W) {
-    if (h->fp32) launch_fused_tw<float, 1>(h, P, xp, xc, pc, pn, W);   // the tile-width knob is an fp64 tuning aid
+    if (h->fused_nt == 512 && !h->fp32) launch_fused_tw<double, 2, 512>(h, P, xp, xc, pc, pn, W);
+    else if (h->fp32) launch_fused_tw<float, 1>(h, P, xp, xc, pc, pn, W);   // the tile-width knob is an fp64 tuning aid
     else if (h->fused_tw == 1) launch_fused_tw<double, 1>(h, P, xp, xc, pc, pn, W);
     else if (h->fused_tw == 2) launch_fused_tw<double, 2>(h, P, xp, xc, pc, pn, W);
     else launch_fused_tw<double, 4>(h, P, xp, xc, pc, pn, W);

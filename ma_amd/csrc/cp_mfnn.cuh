@@ -77,7 +77,7 @@ __device__ __forceinline__ double load_y3_apply_W(const S *__restrict__ y3base, 
 
 // stage the 16 x 16 matrix W (global) into LDS; the caller synchronises
 __device__ __forceinline__ void stage_W(const double *__restrict__ W, double *Wl) {
-    Wl[threadIdx.x] = W[threadIdx.x];   // CP_BLOCK == 256 entries
+    if (threadIdx.x < 256) Wl[threadIdx.x] = W[threadIdx.x];   // 256 entries
 }
 
 // MODE 0: update (writes pout); MODE 1: monitor only (y_new := y_in, nothing written but the partials).

@@ -73,16 +73,19 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
 // Tiles: a workgroup handles TW adjacent image columns x 256/TW rows per step (TW = 4: one column segment of 64 rows per
 // wave). Wider tiles serve the j+1 neighbour loads of waves 0..TW-2 from the next wave's own loads, but make the i+1
 // spill-over line of every wave a miss in the XCD's L2; TW = 1 measured best (see cp_create).
-__host__ __device__ inline int fused_tiles(int m, int nl, int tw) { return ((m + CP_BLOCK / tw - 1) / (CP_BLOCK / tw)) * ((nl + tw - 1) / tw); }
+__host__ __device__ inline int fused_tiles(int m, int nl, int tw, int nt = CP_BLOCK) { return ((m + nt / tw - 1) / (nt / tw)) * ((nl + tw - 1) / tw); }
 
-template <typename S, bool LINEAR, bool FULLK, int TW>
-__global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S *__restrict__ xo,
+// NT = threads per workgroup: 256 (2 workgroups per CU) or 512 (one workgroup per CU, e.g. TW = 2: two adjacent columns
+// of 256 rows side by side, so that half of the j+1 neighbour loads are lines the other half of the workgroup streams)
+template <typename S, bool LINEAR, bool FULLK, int TW, int NT = CP_BLOCK>
+__global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParams P, const S *__restrict__ xo,
                                                              S *__restrict__ xn, const S *__restrict__ pin,
                                                              S *__restrict__ pout, const S *__restrict__ g,
                                                              const S *__restrict__ b, const double *__restrict__ W,
                                                              const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
-    __shared__ double tiles[CP_WAVES * 2 * 16 * CP_TS];
-    __shared__ double red[CP_WAVES * CP_NSCAL];
+    constexpr int NWV = NT / 64;
+    __shared__ double tiles[NWV * 2 * 16 * CP_TS];
+    __shared__ double red[NWV * CP_NSCAL];
     __shared__ double Wl[CP_KMAX * CP_KMAX];
     if (ctrl->stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S
     maxs[DM_Y1 - CP_NSUM] = 0.0; maxs[DM_S1 - CP_NSUM] = 0.0; maxs[PM_VL - CP_NSUM] = 0.0;
     double4_t acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 
-    constexpr int TH = CP_BLOCK / TW;
+    constexpr int TH = NT / TW;
     const int tiles_i = (m + TH - 1) / TH, ntiles = tiles_i * ((P.nl + TW - 1) / TW);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tj = t / tiles_i, ti = t - tj * tiles_i;
@@ -257,9 +260,9 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S
         }
     }
     double *out = part + (size_t)blockIdx.x * CP_PSTRIDE;
-    block_reduce_store<CP_NSUM, CP_NMAX>(sums, maxs, red, out);
-    gram_block_store(acc1, tiles, out + CP_NSCAL);
-    gram_block_store(acc2, tiles, out + CP_NSCAL + 256);
+    block_reduce_store<CP_NSUM, CP_NMAX, NWV>(sums, maxs, red, out);
+    gram_block_store<NWV>(acc1, tiles, out + CP_NSCAL);
+    gram_block_store<NWV>(acc2, tiles, out + CP_NSCAL + 256);
 }
 
 struct EFusedArgs {
