@@ -116,6 +116,18 @@ __device__ __forceinline__ void reduce_partials2(const double *__restrict__ part
     __syncthreads();
 }
 
+// Jacobi rotation (c, s) that annihilates a_pq, from two reciprocal square roots: c^2 = (1 + |d|/h)/2,
+// s = sign(d) a_pq / (h c) with d = a_qq - a_pp, h = |(d, 2 a_pq)|; identity below the rotation threshold.
+__device__ __forceinline__ void jacobi_rot(double app, double aqq, double apq, double &c, double &s) {
+    c = 1.0; s = 0.0;
+    if (apq * apq > 1.0e-34 * fabs(app * aqq) && fabs(apq) > 1.0e-300) {
+        const double d = aqq - app;
+        double h, rh, rc;
+        sqrt_rsqrt(fma(d, d, 4.0 * apq * apq), h, rh);
+        sqrt_rsqrt(fma(0.5 * fabs(d), rh, 0.5), c, rc);
+        s = copysign(1.0, d) * apq * rh * rc;
+    }
+}
 // ---- parallel cyclic Jacobi on a symmetric 16 x 16 matrix in LDS (256 threads) -------------------
 // Round-robin ordering: 15 rounds of 8 disjoint rotations per sweep. On exit diag(G) holds the
 // eigenvalues and (WITH_V) the columns of V the eigenvectors: G_in = V diag V'.
@@ -140,14 +152,9 @@ __device__ void jacobi16(double (*G)[17], double (*V)[17], double (*cs)[2], int 
                 else { p = (r + t) % 15; q = (r - t + 15) % 15; }
                 if (p > q) { const int tmp = p; p = q; q = tmp; }
                 const double app = G[p][p], aqq = G[q][q], apq = G[p][q];
-                double c = 1.0, s = 0.0;
-                if (fabs(apq) > 1.0e-17 * sqrt(fabs(app * aqq)) && fabs(apq) > 1.0e-300) {
-                    const double th = (aqq - app) / (2.0 * apq);
-                    const double tt = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
-                    c = 1.0 / sqrt(tt * tt + 1.0);
-                    s = tt * c;
-                    *rotflag = 1;
-                }
+                double c, s;
+                jacobi_rot(app, aqq, apq, c, s);
+                if (s != 0.0) *rotflag = 1;
                 cs[t][0] = c; cs[t][1] = s; pq[t][0] = p; pq[t][1] = q;
             }
             __syncthreads();
@@ -190,16 +197,6 @@ __device__ void jacobi16(double (*G)[17], double (*V)[17], double (*cs)[2], int 
 // d = aqq - app, h = |(d, 2 apq)|) instead of three divisions and three square roots in sequence -- that dependent
 // chain, not the barriers, bounded the previous version. G[mid], V[mid] hold the result; Gb, Vb are the second
 // buffers, cs the published rotations. A sweep starts only if an off-diagonal entry is above the threshold somewhere.
-__device__ __forceinline__ void jacobi_rot(double app, double aqq, double apq, double &c, double &s) {
-    c = 1.0; s = 0.0;
-    if (apq * apq > 1.0e-34 * fabs(app * aqq) && fabs(apq) > 1.0e-300) {
-        const double d = aqq - app;
-        double h, rh, rc;
-        sqrt_rsqrt(fma(d, d, 4.0 * apq * apq), h, rh);
-        sqrt_rsqrt(fma(0.5 * fabs(d), rh, 0.5), c, rc);
-        s = copysign(1.0, d) * apq * rh * rc;
-    }
-}
 __device__ void jacobi16_pair(double (*G)[16][17], double (*V)[16][17], double (*Gb)[16][17], double (*Vb)[16][17],
                               double (*cs)[16][2]) {
     const int t = threadIdx.x, mid = t >> 8, tl = t & 255;
@@ -251,13 +248,14 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_eig(EigArgs A, const doub
     __shared__ int pq[8][2], rotflag;
     if (ctrl->stop) return;
     const int t = threadIdx.x;
+    __shared__ double S[16], z[16], zs[16];   // dynamically indexed below: LDS, not scratch
     reduce_partials(part, A.nblk, G, sc, stage);
+    if (t >= 256) return;        // the eigensolve needs 256 threads; ended waves do not take part in barriers
     jacobi16<true>(G, V, cs, pq, &rotflag);
     if (t == 0) {
         const int K = A.K;
         const double nu = ctrl->nu;
         const double mu_ = nu * A.sigma;                  // NNE/nuclear_norm_constraint.m:72
-        double S[16], z[16], zs[16];
         double sumz = 0.0;
         for (int i = 0; i < K; ++i) {
             S[i] = sqrt(fmax(G[i][i], 0.0));
@@ -361,8 +359,9 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_fin(EigArgs A, const doub
                 acc += qa * row;
             }
         }
+        if (t >= 256) return;    // the eigensolve needs 256 threads; ended waves do not take part in barriers
         __syncthreads();
-        if (t < 256) G[a][bq] = acc;
+        G[a][bq] = acc;
         __syncthreads();
     }
     jacobi16<false>(G, nullptr, cs, pq, &rotflag);
