@@ -728,6 +728,16 @@ static void launch_mf_primal(cp_engine *h, const MfParams &P, const double *xc, 
                            (const CpCtrl *)h->ctrl, cc, h->part);
 }
 
+// warm start of the eigensolves from the previous iteration's bases; a cold start every 128 iterations (and at the first
+// one) keeps the accumulated product of rotations orthogonal to rounding (the drift is ~16 eps per warm iteration)
+static inline int efused_warm(int n) { return (n > 1 && (n & 127) != 1) ? 1 : 0; }
+// split passes: k_mf_eig keeps its basis in vwarm[0..255], k_mf_fin in vwarm[256..511]
+static inline EigArgs with_warm(EigArgs A, const cp_engine *h, int n, int slot) {
+    A.vwarm = h->vwarm + 256 * slot;
+    A.warm = efused_warm(n);
+    return A;
+}
+
 static EigArgs eig_args(const cp_engine *h, const MfParams &P, int rp, int rd, int check, int update, int newbuf,
                         double tol, int monitor = 0, int compute_cn = 0) {
     EigArgs A;
@@ -736,6 +746,7 @@ static EigArgs eig_args(const cp_engine *h, const MfParams &P, int rp, int rd, i
     A.tau = P.tau;
     A.nblk = h->nblk; A.K = h->K; A.reg = h->reg; A.rp = rp; A.rd = rd; A.check_stop = check; A.update = update;
     A.newbuf = newbuf; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2; A.sigma = P.sigma; A.Ntot = P.Ntot;
+    A.vwarm = nullptr; A.warm = 0;   // cold eigensolve, nothing kept (monitor rows, start-up); see eig_args_warm
     return A;
 }
 
@@ -748,15 +759,16 @@ static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int
         launch_mf_dual<0>(h, P, h->X[cur], h->X[nxt], h->P[cur], h->P[nxt], h->W[cur], cur, nxt);
         CPCHK(timer_end(h, T_DUAL));
         CPCHK(timer_begin(h, T_EIG));
-        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, n - 1, n, check, 0, 0, tol),
-                           h->part, ctrl, h->W[nxt], h->hist_p, h->hist_d);
+        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream,
+                           with_warm(eig_args(h, P, n - 1, n, check, 0, 0, tol), h, n, 0), h->part, ctrl, h->W[nxt], h->hist_p,
+                           h->hist_d);
         CPCHK(timer_end(h, T_EIG));
         CPCHK(timer_begin(h, T_PRIMAL));
         launch_mf_primal<0>(h, P, h->X[cur], h->X[nxt], h->P[nxt], h->W[nxt], cur);
         CPCHK(timer_end(h, T_PRIMAL));
         CPCHK(timer_begin(h, T_FIN));
-        hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, n, n, 0, 1, nxt, tol),
-                           h->part, ctrl, h->hist_p, h->hist_d);
+        hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream,
+                           with_warm(eig_args(h, P, n, n, 0, 1, nxt, tol), h, n, 1), h->part, ctrl, h->hist_p, h->hist_d);
         CPCHK(timer_end(h, T_FIN));
     }
     HIPCHK(hipGetLastError());
@@ -819,9 +831,6 @@ static const double *fused_partials(cp_engine *h, int *rows) {
     return h->part2;
 }
 
-// warm start of the eigensolves from the previous iteration's bases; a cold start every 128 iterations (and at the first
-// one) keeps the accumulated product of rotations orthogonal to rounding (the drift is ~16 eps per warm iteration)
-static inline int efused_warm(int n) { return (n > 1 && (n & 127) != 1) ? 1 : 0; }
 
 // ---- fused NN-TV path: F_0 = dual step 1 alone, then one k_mf_fused_tv + k_mf_efused per iteration -------------
 static int mf_fused_start(cp_engine *h, const MfParams &P, double tol) {
@@ -1659,7 +1668,7 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             break;
         }
         case CP_STAGE_SPLIT_EIG: {
-            EigArgs A = eig_args(h, P, n - 1, n, check_stop, 0, 0, tol);
+            EigArgs A = with_warm(eig_args(h, P, n - 1, n, check_stop, 0, 0, tol), h, n, 0);
             A.nblk = world;
             hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->W[n & 1], h->hist_p,
                                h->hist_d);
@@ -1674,7 +1683,7 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             break;
         }
         case CP_STAGE_SPLIT_FIN: {
-            EigArgs A = eig_args(h, P, n, n, 0, 1, n & 1, tol);
+            EigArgs A = with_warm(eig_args(h, P, n, n, 0, 1, n & 1, tol), h, n, 1);
             A.nblk = world;
             hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->hist_p, h->hist_d);
             break;

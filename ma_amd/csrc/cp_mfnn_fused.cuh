@@ -306,34 +306,7 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
     }
     if (t >= 512) return;        // the eigensolves need 2 x 256 threads; ended waves do not take part in barriers
     __syncthreads();
-    {
-        // The Gram matrices change little from one iteration to the next: rotate them into the previous
-        // eigenvector bases first (G' = V0' G V0 is then almost diagonal and needs 2-3 sweeps instead of ~8).
-        const int mid = t >> 8, tl = t & 255, r = tl >> 4, c = tl & 15;
-        VV[mid][r][c] = (r == c) ? 1.0 : 0.0;
-        if (A.warm) {
-            V0[mid][r][c] = vwarm[mid * 256 + tl];
-            __syncthreads();
-            double acc = 0.0;
-            for (int i = 0; i < 16; ++i) acc += GG[mid][r][i] * V0[mid][i][c];
-            Tm[mid][r][c] = acc;
-            __syncthreads();
-            acc = 0.0;
-            for (int i = 0; i < 16; ++i) acc += V0[mid][i][r] * Tm[mid][i][c];
-            __syncthreads();
-            GG[mid][r][c] = acc;
-        }
-        __syncthreads();
-        jacobi16_pair(GG, VV, Tm, VB, cs);
-        if (A.warm) {   // eigenvectors in the original basis: V0 * V
-            double acc = 0.0;
-            for (int i = 0; i < 16; ++i) acc += V0[mid][r][i] * VV[mid][i][c];
-            __syncthreads();
-            VV[mid][r][c] = acc;
-        }
-        vwarm[mid * 256 + tl] = (A.warm) ? VV[mid][r][c] : VV[mid][r][c];
-        __syncthreads();
-    }
+    eig16_warm(GG, VV, V0, Tm, VB, cs, vwarm, A.warm);   // both Gram matrices side by side, warm-started
     if (t == 0) {
         const int K = A.K;
         const double nu = ctrl->nu, mu_ = nu * A.sigma;   // NNE/nuclear_norm_constraint.m:72

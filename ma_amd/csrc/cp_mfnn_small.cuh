@@ -16,6 +16,8 @@ struct EigArgs {
     int compute_cn;      // eig: store the mean of the next un-projected u into ctrl->cn (start of the fused passes)
     double tau;
     double tol, mu1, mu2, sigma, Ntot;
+    double *vwarm;       // 256 doubles: eigenvector basis of this kernel's matrix from the previous iteration (or null)
+    int warm;            // start the eigensolve from vwarm (see eig16_warm)
 };
 
 // ---- reduction of the per-block partial buffer (fixed order => deterministic) -------------------
@@ -241,17 +243,53 @@ __device__ void jacobi16_pair(double (*G)[16][17], double (*V)[16][17], double (
     __syncthreads();
 }
 
+// Eigen-decomposition of NM (1 or 2) symmetric 16 x 16 matrices GG[mid] on NM*256 live threads, optionally warm-started:
+// the matrices of consecutive CP iterations differ little, so G' = V0' G V0 with the previous eigenvectors V0 is almost
+// diagonal and needs 2-3 sweeps instead of ~8; the eigenvectors in the original basis are V0 * V. On exit diag(GG[mid])
+// holds the eigenvalues, VV[mid] the eigenvectors; they are also stored to vwarm (if given) for the next call.
+// V0, Tm, VB: LDS scratch matrices; cs: rotations of a round. Ends with a barrier.
+__device__ __forceinline__ void eig16_warm(double (*GG)[16][17], double (*VV)[16][17], double (*V0)[16][17],
+                                           double (*Tm)[16][17], double (*VB)[16][17], double (*cs)[16][2],
+                                           double *__restrict__ vwarm, int warm) {
+    const int t = threadIdx.x, mid = t >> 8, tl = t & 255, r = tl >> 4, c = tl & 15;
+    const bool w = warm && vwarm;
+    VV[mid][r][c] = (r == c) ? 1.0 : 0.0;
+    if (w) {
+        V0[mid][r][c] = vwarm[mid * 256 + tl];
+        __syncthreads();
+        double acc = 0.0;
+        for (int i = 0; i < 16; ++i) acc += GG[mid][r][i] * V0[mid][i][c];
+        Tm[mid][r][c] = acc;
+        __syncthreads();
+        acc = 0.0;
+        for (int i = 0; i < 16; ++i) acc += V0[mid][i][r] * Tm[mid][i][c];
+        __syncthreads();
+        GG[mid][r][c] = acc;
+    }
+    __syncthreads();
+    jacobi16_pair(GG, VV, Tm, VB, cs);
+    if (w) {   // eigenvectors in the original basis: V0 * V
+        double acc = 0.0;
+        for (int i = 0; i < 16; ++i) acc += V0[mid][r][i] * VV[mid][i][c];
+        __syncthreads();
+        VV[mid][r][c] = acc;
+    }
+    if (vwarm) vwarm[mid * 256 + tl] = VV[mid][r][c];
+    __syncthreads();
+}
+
 // ---- dual-side finalisation: W for y3, F* values, primal row rp, stop rule ------------------------
 __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_eig(EigArgs A, const double *__restrict__ part, CpCtrl *ctrl,
                                                            double *__restrict__ Wout, double *hist_p, double *hist_d) {
-    __shared__ double G[16][17], V[16][17], sc[CP_NSCAL], cs[8][2], dvec[16], stage[CP_RED_THREADS];
-    __shared__ int pq[8][2], rotflag;
+    __shared__ double GG[1][16][17], VV[1][16][17], V0[1][16][17], Tm[1][16][17], VB[1][16][17], cs[1][16][2], sc[CP_NSCAL],
+        dvec[16], stage[CP_RED_THREADS];
+    double (*G)[17] = GG[0], (*V)[17] = VV[0];
     if (ctrl->stop) return;
     const int t = threadIdx.x;
     __shared__ double S[16], z[16], zs[16];   // dynamically indexed below: LDS, not scratch
     reduce_partials(part, A.nblk, G, sc, stage);
     if (t >= 256) return;        // the eigensolve needs 256 threads; ended waves do not take part in barriers
-    jacobi16<true>(G, V, cs, pq, &rotflag);
+    eig16_warm(GG, VV, V0, Tm, VB, cs, A.vwarm, A.warm);
     if (t == 0) {
         const int K = A.K;
         const double nu = ctrl->nu;
@@ -337,8 +375,9 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_eig(EigArgs A, const doub
 // ---- primal-side finalisation: offsets c, feasibility of B*L, G* measures, dual row rd ------------
 __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_fin(EigArgs A, const double *__restrict__ part, CpCtrl *ctrl,
                                                            double *hist_p, double *hist_d) {
-    __shared__ double G[16][17], sc[CP_NSCAL], cs[8][2], stage[CP_RED_THREADS];
-    __shared__ int pq[8][2], rotflag;
+    __shared__ double GG[1][16][17], VV[1][16][17], V0[1][16][17], Tm[1][16][17], VB[1][16][17], cs[1][16][2], sc[CP_NSCAL],
+        stage[CP_RED_THREADS];
+    double (*G)[17] = GG[0];
     if (ctrl->stop) return;
     reduce_partials(part, A.nblk, G, sc, stage);
     {
@@ -364,7 +403,7 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_fin(EigArgs A, const doub
         G[a][bq] = acc;
         __syncthreads();
     }
-    jacobi16<false>(G, nullptr, cs, pq, &rotflag);
+    eig16_warm(GG, VV, V0, Tm, VB, cs, A.vwarm, A.warm);
     if (threadIdx.x == 0) {
         const double nu = ctrl->nu;
         double sumS = 0.0;
