@@ -27,8 +27,9 @@ struct EigArgs {
 #define CP_RED_THREADS 1024
 __device__ __forceinline__ void reduce_partials(const double *__restrict__ part, int nblk, double (*G)[17],
                                                 double *sc, double *stage) {
+    __shared__ double stage_sc[CP_RED_THREADS];
     const int t = threadIdx.x;
-    {
+    {   // one phase: the loads of the Gram entries and of the scalars are all in flight before the first barrier
         const int grp = t >> 8, e = t & 255;
         double a[8];
 #pragma unroll
@@ -40,31 +41,29 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
             for (int u = 0; u < 8; ++u) a[u] += src[(size_t)(bI + 4 * u) * CP_PSTRIDE];
         }
         for (int u = 0; bI < nblk; bI += 4, ++u) a[u & 7] += src[(size_t)bI * CP_PSTRIDE];
-        stage[t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    }
-    __syncthreads();
-    if (t < 256) G[t >> 4][t & 15] = (stage[t] + stage[256 + t]) + (stage[512 + t] + stage[768 + t]);
-    __syncthreads();
-    {
         const int slot = t & 31, sub = t >> 5;   // 32 sub-groups of 32 threads (CP_NSCAL <= 32 slots used)
         const bool is_sum = slot < CP_NSUM;
         double v = is_sum ? 0.0 : -1.0e300;
         if (slot < CP_NSCAL)
-            for (int bI = sub; bI < nblk; bI += 32) {
-                const double o = part[(size_t)bI * CP_PSTRIDE + slot];
+            for (int bJ = sub; bJ < nblk; bJ += 32) {
+                const double o = part[(size_t)bJ * CP_PSTRIDE + slot];
                 v = is_sum ? v + o : fmax(v, o);
             }
-        stage[t] = v;
+        stage[t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        stage_sc[t] = v;
     }
     __syncthreads();
-    if (t < CP_NSCAL) {
-        const bool is_sum = t < CP_NSUM;
-        double v = stage[t];
+    if (t < 256) {
+        G[t >> 4][t & 15] = (stage[t] + stage[256 + t]) + (stage[512 + t] + stage[768 + t]);
+    } else if (t < 256 + CP_NSCAL) {
+        const int q = t - 256;
+        const bool is_sum = q < CP_NSUM;
+        double v = stage_sc[q];
         for (int sub = 1; sub < 32; ++sub) {
-            const double o = stage[sub * 32 + t];
+            const double o = stage_sc[sub * 32 + q];
             v = is_sum ? v + o : fmax(v, o);
         }
-        sc[t] = v;
+        sc[q] = v;
     }
     __syncthreads();
 }
