@@ -30,3 +30,22 @@ def test_rccl_backend_single_rank():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=250)
     print(r.stdout[-1500:], r.stderr[-1500:])
     assert r.returncode == 0 and '"metric"' in r.stdout
+
+
+@pytest.mark.parametrize("world,reg", [(2, "tv"), (3, "curvature")])
+def test_bench_row_slabs_multi_rank(world, reg):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per slab), except that the
+    ranks share one GPU and talk through gloo: one JSON line from rank 0, strong scaling, all ranks finish."""
+    import json
+    env = dict(os.environ, CP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(29450 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size",
+           "192", "--k", "6", "--reg", reg, "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=250)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["parallelism"] == f"row slabs x{world}"
