@@ -48,6 +48,31 @@ def measured_copy_gbs(dev):
     return best
 
 
+class _StdoutToStderr:
+    """stdout carries the one JSON line of the contract; RCCL prints its version banner (NCCL_DEBUG=VERSION) with printf
+    when a communicator is created, so file descriptor 1 points at stderr while the process group comes up"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def _init_process_group(dist, torch, backend, local_rank):
+    with _StdoutToStderr():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()                      # communicators exist (and have printed) before stdout comes back
+            torch.cuda.synchronize()
+        else:
+            dist.init_process_group(backend)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,10 +148,7 @@ def main_batch(args):
     if backend == "gloo":
         local_rank = 0
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        _init_process_group(dist, torch, backend, local_rank)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
@@ -208,10 +230,7 @@ def main():
     if backend == "gloo":
         local_rank = 0
     if world > 1 or os.environ.get("CP_FORCE_SLAB_PATH", "0") == "1":
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        _init_process_group(dist, torch, backend, local_rank)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
