@@ -98,6 +98,22 @@ def _load():
     return lib
 
 
+def _torch_first():
+    """The PyTorch-ROCm wheel bundles its own HIP runtime next to the system one this library links. The two coexist in a
+    process only if torch initialises its device BEFORE libcpengine.so is loaded (loaded the other way round, whichever
+    runtime comes second reports that there is no GPU). So: if torch is importable and sees a GPU, let it come first.
+    CP_ENGINE_NO_TORCH=1 skips this (a process that never touches torch.cuda does not need it)."""
+    if os.environ.get("CP_ENGINE_NO_TORCH", "0") == "1":
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
+_torch_first()
 lib = _load()
 EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_images", "cp_set_primal", "cp_set_dual",
             "cp_linearize", "cp_get_linearization", "cp_set_linearization", "cp_apply_A", "cp_apply_At", "cp_set_nu", "cp_singular_values", "cp_norm_estimate", "cp_solve",
@@ -125,26 +141,6 @@ def _dptr(a):
 def _f64(a):
     """host vector in MATLAB (column-major) order as a contiguous float64 array"""
     return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
-
-
-_torch_checked = False
-
-
-def _torch_first():
-    """If PyTorch-ROCm is loaded in this process, let it initialise its device before the engine's first HIP call: the
-    torch wheel bundles its own HIP runtime, and it only finds the GPUs when it comes first."""
-    global _torch_checked
-    if _torch_checked:
-        return
-    _torch_checked = True
-    import sys
-    t = sys.modules.get("torch")
-    if t is not None:
-        try:
-            if t.cuda.is_available():
-                t.cuda.init()
-        except Exception:
-            pass
 
 
 class Engine:
@@ -182,7 +178,6 @@ class Engine:
             self.ny = 2 * nc * m * n * batch
             self.cols = 5
         self._h = C.c_void_p()
-        _torch_first()
         _chk(lib.cp_create(C.byref(d), C.byref(self._h)))
 
     def close(self):
