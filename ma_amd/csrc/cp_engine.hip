@@ -211,6 +211,11 @@ static int grid_for(const cp_engine *h) {
 
 // ------------------------------------------------------------------------------------------------
 extern "C" const char *cp_last_error(void) { return g_err.c_str(); }
+#ifdef CP_EPROF
+extern "C" int cp_debug_eprof(unsigned long long *out) {   // experiments only: phase timestamps of the last k_mf_efused
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eprof), 32 * sizeof(unsigned long long));
+}
+#endif
 extern "C" const char *cp_version(void) { return "cpengine 0.1 (gfx950, fp64)"; }
 
 extern "C" int cp_destroy(cp_handle h) {
@@ -796,37 +801,39 @@ static void launch_fused(cp_engine *h, const MfParams &P, const double *xp, doub
 
 // First stage of the reduction of the fused kernel's partial rows: output row r = fixed-order sum (slots < CP_NSUM and
 // the Gram entries) / maximum (slots CP_NSUM..CP_NSCAL-1) of input rows [r*CP_S1_GROUP, (r+1)*CP_S1_GROUP).
+// blockIdx.y selects a chunk of 256 columns; a thread owns one column and keeps 16 loads in flight (the kernel is a few
+// dependent round trips long: with one workgroup per row group walking its three column chunks in turn it took 13 us).
 __global__ __launch_bounds__(256) void k_mf_reduce_stage1(int nrows, const double *__restrict__ part, double *__restrict__ out) {
     const int r0 = blockIdx.x * CP_S1_GROUP, r1 = min(nrows, r0 + CP_S1_GROUP);
-    for (int c = threadIdx.x; c < CP_PSTRIDE; c += 256) {
-        const bool is_max = (c >= CP_NSUM && c < CP_NSCAL);
-        double a[8];
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= CP_PSTRIDE) return;
+    const bool is_max = (c >= CP_NSUM && c < CP_NSCAL);
+    double a[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = is_max ? -1.0e300 : 0.0;
-        int r = r0;
-        for (; r + 8 <= r1; r += 8) {
+    for (int u = 0; u < 16; ++u) a[u] = is_max ? -1.0e300 : 0.0;
+    for (int r = r0; r < r1; r += 16) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
+            if (r + u < r1) {   // uniform
                 const double o = part[(size_t)(r + u) * CP_PSTRIDE + c];
                 a[u] = is_max ? fmax(a[u], o) : a[u] + o;
             }
         }
-        for (int u = 0; r < r1; ++r, ++u) {
-            const double o = part[(size_t)r * CP_PSTRIDE + c];
-            a[u] = is_max ? fmax(a[u], o) : a[u] + o;
-        }
-        double v;
-        if (is_max) v = fmax(fmax(fmax(a[0], a[1]), fmax(a[2], a[3])), fmax(fmax(a[4], a[5]), fmax(a[6], a[7])));
-        else v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-        out[(size_t)blockIdx.x * CP_PSTRIDE + c] = v;
     }
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+        for (int u = 0; u < w; ++u) a[u] = is_max ? fmax(a[u], a[u + w]) : a[u] + a[u + w];
+    out[(size_t)blockIdx.x * CP_PSTRIDE + c] = a[0];
 }
 
-// partial rows of the last k_mf_fused_tv launch as the single-workgroup kernels read them (after stage 1 if needed)
+// partial rows of the last k_mf_fused_tv launch as the single-workgroup kernels read them (after stage 1 if needed:
+// k_mf_efused alone reads about 18 rows per microsecond)
 static const double *fused_partials(cp_engine *h, int *rows) {
-    if (h->nblk_fused <= 512) { *rows = h->nblk_fused; return h->part; }
+    if (h->nblk_fused <= 128) { *rows = h->nblk_fused; return h->part; }
     const int r2 = (h->nblk_fused + CP_S1_GROUP - 1) / CP_S1_GROUP;
-    hipLaunchKernelGGL(k_mf_reduce_stage1, dim3(r2), dim3(256), 0, h->stream, h->nblk_fused, h->part, h->part2);
+    hipLaunchKernelGGL(k_mf_reduce_stage1, dim3(r2, (CP_PSTRIDE + 255) / 256), dim3(256), 0, h->stream, h->nblk_fused,
+                       h->part, h->part2);
     *rows = r2;
     return h->part2;
 }

@@ -277,75 +277,42 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
                                                               CpCtrl *ctrl, double *__restrict__ Wout, double *hist_p,
                                                               double *hist_d, double *__restrict__ vwarm) {
     // GG[0] = Gram(y3~), GG[1] = deflated Gram(B*L); VV: accumulated rotations; V0: warm-start bases; Tm: scratch
-    // (Tm doubles as the second G buffer of the eigensolve, VB is its second V buffer)
-    __shared__ double GG[2][16][17], VV[2][16][17], V0[2][16][17], Tm[2][16][17], VB[2][16][17], G2[16][17], sc[CP_NSCAL],
+    __shared__ double GG[2][16][17], VV[2][16][17], V0[2][16][17], Tm[2][16][17], G2[16][17], sc[CP_NSCAL],
         dvec[16], stage[CP_RED_THREADS], stage2[CP_RED_THREADS];
     double (*G)[17] = GG[0], (*V)[17] = VV[0], (*G2h)[17] = GG[1];
-    __shared__ double cs[2][16][2];             // rotations of the current Jacobi round, per index
-    __shared__ double Sv[16], zv[16], zs[16];   // l1-ball projection of the singular values (dynamically indexed: LDS)
-    __shared__ double res[4];   // spmax, con3
-    if (ctrl->stop) return;
+    __shared__ double zv[16], zs[16];   // l1-ball projection of the singular values
+    __shared__ double svl[16];          // singular values of B*L_n
+    __shared__ double res[4];           // largest singular value of the prox, of the input
     const int t = threadIdx.x;
+    // both control words are requested before the reduction's loads (one global round trip less on the critical path);
+    // a stopped solve leaves after the reduction's barriers (it reads a stale partial buffer, nothing is written)
+    const int stopped = ctrl->stop;
+    const double nu = ctrl->nu;
+#ifdef CP_EPROF
+    if (t == 0) g_eprof[20] = 0;
+#endif
+    EPROF(0);
     reduce_partials2(part, A.nblk, G, G2, sc, stage, stage2);   // Gram(y3~_{n+1}), Gram(B*L_n) and the scalars
-    if (t < 256) {   // Gram(B*L_n) restricted to the complement of (1,..,1) (see k_mf_fin)
-        const int a = t >> 4, bq = t & 15, K = A.K;
-        double acc = 0.0;
-        if (a < K - 1 && bq < K - 1) {
-            const double na = 1.0 / sqrt((double)(a + 1) * (a + 2)), nb = 1.0 / sqrt((double)(bq + 1) * (bq + 2));
-            for (int i = 0; i <= a + 1; ++i) {
-                const double qa = (i <= a) ? na : -(double)(a + 1) * na;
-                double row = 0.0;
-                for (int j = 0; j <= bq + 1; ++j) {
-                    const double qb = (j <= bq) ? nb : -(double)(bq + 1) * nb;
-                    row += G2[i][j] * qb;
-                }
-                acc += qa * row;
-            }
-        }
-        G2h[a][bq] = acc;
-    }
+    if (stopped) return;
+    EPROF(1);
     if (t >= 512) return;        // the eigensolves need 2 x 256 threads; ended waves do not take part in barriers
+    // Gram(B*L_n) restricted to the complement of (1,..,1) (see helmert_rows)
+    if (t < 256) helmert_rows(G2, Tm[1], A.K, t >> 4, t & 15);
     __syncthreads();
-    eig16_warm(GG, VV, V0, Tm, VB, cs, vwarm, A.warm);   // both Gram matrices side by side, warm-started
-    if (t == 0) {
-        const int K = A.K;
-        const double nu = ctrl->nu, mu_ = nu * A.sigma;   // NNE/nuclear_norm_constraint.m:72
-        double *S = Sv, *z = zv;
-        double sumz = 0.0;
-        for (int i = 0; i < K; ++i) {
-            S[i] = sqrt(fmax(G[i][i], 0.0));
-            z[i] = S[i] / mu_;
-            zs[i] = z[i];
-            sumz += z[i];
-            ctrl->sv[i] = S[i];
-        }
-        double theta = 0.0;
-        const bool inside = (sumz <= 1.0);                // NNE/l1ball_projection.m:28
-        if (!inside) {
-            for (int i = 1; i < K; ++i) {
-                const double v = zs[i];
-                int j = i - 1;
-                while (j >= 0 && zs[j] < v) { zs[j + 1] = zs[j]; --j; }
-                zs[j + 1] = v;
-            }
-            double cum = 0.0;
-            for (int i = 0; i < K; ++i) {
-                cum += zs[i];
-                const double th = (cum - 1.0) / (double)(i + 1);
-                if (zs[i] - th > 0.0) theta = th;
-            }
-        }
-        double spmax = 0.0;
-        for (int i = 0; i < 16; ++i) dvec[i] = 0.0;
-        for (int i = 0; i < K; ++i) {
-            const double Pi = inside ? z[i] : fmax(z[i] - theta, 0.0);
-            const double sp = S[i] - mu_ * Pi;                            // :76
-            dvec[i] = (S[i] > 0.0) ? (mu_ * Pi) / S[i] : 0.0;
-            spmax = fmax(spmax, sp);
-        }
-        res[0] = spmax;
+    if (t < 256) helmert_cols(Tm[1], G2h, A.K, t >> 4, t & 15);
+    __syncthreads();
+    EPROF(2);
+    eig16_warm<2>(GG, VV, V0, Tm, vwarm, A.warm);   // both Gram matrices side by side, warm-started
+    EPROF(5);
+    if (t < 64) l1ball_scale16(G, A.K, nu * A.sigma, zv, zs, dvec, res, ctrl->sv);   // NNE/nuclear_norm_constraint.m:72
+    else if (t < 80) {   // singular values of B*L_n (K-1 after the deflation), one lane each
+        const int i = t - 64;
+        const double sL = (i < A.K - 1) ? sqrt(fmax(G2h[i][i], 0.0)) : 0.0;
+        svl[i] = sL;
+        if (i < A.K) ctrl->svL[i] = sL;
     }
     __syncthreads();
+    EPROF(6);
     if (t < 256) {   // W_{n+1} = I - V diag(d) V'
         const int k = t >> 4, kp = t & 15;
         double a = (k == kp) ? 1.0 : 0.0;
@@ -354,14 +321,8 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
         Wout[k * CP_KMAX + kp] = a;
     }
     if (t == 0) {
-        const double nu = ctrl->nu;
         double sumS = 0.0;
-        for (int i = 0; i < A.K; ++i) ctrl->svL[i] = 0.0;
-        for (int i = 0; i < A.K - 1; ++i) {
-            const double s = sqrt(fmax(G2h[i][i], 0.0));
-            ctrl->svL[i] = s;
-            sumS += s;
-        }
+        for (int i = 0; i < A.K - 1; ++i) sumS += svl[i];
         const int n = A.n;
         double *hp = hist_p + (size_t)n * CP_HCOLS_MF;
         double *hd = hist_d + (size_t)n * CP_HCOLS_MF, *hd1 = hist_d + (size_t)(n + 1) * CP_HCOLS_MF;
@@ -399,4 +360,5 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
             if (ok) { ctrl->stop = 1; ctrl->stop_iter = n; }
         }
     }
+    EPROF(7);
 }

@@ -4,6 +4,14 @@
 #pragma once
 #include "cp_mfnn.cuh"
 
+#ifdef CP_EPROF
+__device__ unsigned long long g_eprof[32];
+#define EPROF(i) do { if (threadIdx.x == 0) g_eprof[i] = wall_clock64(); } while (0)
+#define EPROF_ADD(i) do { if (threadIdx.x == 0) g_eprof[i] += 1; } while (0)
+#else
+#define EPROF(i)
+#define EPROF_ADD(i)
+#endif
 #define CP_HCOLS_MF 7   // [p, F1, F2, F3, G, F_con, G_con] / [q, F1*, F2*, F3*, G*, F*_con, G*_con]
 
 struct EigArgs {
@@ -117,17 +125,27 @@ __device__ __forceinline__ void reduce_partials2(const double *__restrict__ part
     __syncthreads();
 }
 
-// Jacobi rotation (c, s) that annihilates a_pq, from two reciprocal square roots: c^2 = (1 + |d|/h)/2,
-// s = sign(d) a_pq / (h c) with d = a_qq - a_pp, h = |(d, 2 a_pq)|; identity below the rotation threshold.
+// Jacobi rotation (c, s) that annihilates a_pq: with d = a_qq - a_pp, h = |(d, 2 a_pq)| and w = |d| + h the half-angle
+// vector is (c, s) = (w, sign(d) 2 a_pq) / |(w, 2 a_pq)|. Branch-free (two calls interleave as independent instruction
+// streams) and built on v_rsq_f64: h needs no more than one Newton step (an error in h only perturbs the angle, the
+// normalisation below restores c^2 + s^2 = 1), the normalising reciprocal square root gets two. Identity below the
+// rotation threshold |a_pq| <= eps sqrt(a_pp a_qq) (the relative criterion of one-sided / positive definite Jacobi;
+// a tighter one only adds a sweep that rotates rounding noise).
+#define CP_JACOBI_TOL2 4.9e-32   // (2^-52)^2
 __device__ __forceinline__ void jacobi_rot(double app, double aqq, double apq, double &c, double &s) {
-    c = 1.0; s = 0.0;
-    if (apq * apq > 1.0e-34 * fabs(app * aqq) && fabs(apq) > 1.0e-300) {
-        const double d = aqq - app;
-        double h, rh, rc;
-        sqrt_rsqrt(fma(d, d, 4.0 * apq * apq), h, rh);
-        sqrt_rsqrt(fma(0.5 * fabs(d), rh, 0.5), c, rc);
-        s = copysign(1.0, d) * apq * rh * rc;
-    }
+    const bool rot = (apq * apq > CP_JACOBI_TOL2 * fabs(app * aqq)) && (fabs(apq) > 1.0e-300);
+    const double d = aqq - app, a2 = apq + apq;
+    const double x = rot ? fma(d, d, a2 * a2) : 1.0;
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y0;                                   // ~ sqrt(x)
+    const double h = fma(fma(-g0, g0, x), 0.5 * y0, g0);        // one Newton step
+    const double w = fabs(d) + h;
+    const double x2 = rot ? fma(w, w, a2 * a2) : 1.0;
+    double y = __builtin_amdgcn_rsq(x2);
+    y = fma(0.5 * y, fma(-x2 * y, y, 1.0), y);
+    y = fma(0.5 * y, fma(-x2 * y, y, 1.0), y);
+    c = rot ? w * y : 1.0;
+    s = rot ? copysign(a2, d * apq) * y : 0.0;
 }
 // ---- parallel cyclic Jacobi on a symmetric 16 x 16 matrix in LDS (256 threads) -------------------
 // Round-robin ordering: 15 rounds of 8 disjoint rotations per sweep. On exit diag(G) holds the
@@ -190,66 +208,157 @@ __device__ void jacobi16(double (*G)[17], double (*V)[17], double (*cs)[2], int 
     }
 }
 
-// Two symmetric 16 x 16 eigenproblems side by side on 512 threads (matrix mid = t >> 8, one thread per entry).
-// Cyclic Jacobi with the round-robin ordering of jacobi16. A round applies its 8 disjoint rotations as ONE two-sided
-// update G' = J' G J, V' = V J per entry, read from one buffer and written to the other: two barriers per round (after
-// the 16 threads of row 0 have published the rotation of every index, after the update) instead of three, and G and V
-// move together. The rotation comes from two reciprocal square roots (c^2 = (1 + |d|/h)/2, s = sign(d) apq / (h c) with
-// d = aqq - app, h = |(d, 2 apq)|) instead of three divisions and three square roots in sequence -- that dependent
-// chain, not the barriers, bounded the previous version. G[mid], V[mid] hold the result; Gb, Vb are the second
-// buffers, cs the published rotations. A sweep starts only if an off-diagonal entry is above the threshold somewhere.
-__device__ void jacobi16_pair(double (*G)[16][17], double (*V)[16][17], double (*Gb)[16][17], double (*Vb)[16][17],
-                              double (*cs)[16][2]) {
-    const int t = threadIdx.x, mid = t >> 8, tl = t & 255;
-    const int a = tl >> 4, b = tl & 15;
-    {
-        const double sy = 0.5 * (G[mid][a][b] + G[mid][b][a]);
-        __syncthreads();
-        G[mid][a][b] = sy;
+// Ordering point for LDS traffic between the lanes of ONE wavefront (its DS instructions execute in order; this only
+// keeps the compiler from moving accesses across it). No s_barrier.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Cyclic Jacobi on a symmetric 16 x 16 matrix in LDS by ONE wavefront, in place, without workgroup barriers (the
+// barrier-per-round versions spent 0.7 us per round, 30 us per warm-started call: k_mf_efused is pure latency).
+// Round-robin ordering of jacobi16: 15 rounds of 8 disjoint index pairs per sweep. The lanes form an 8 x 8 grid; in a
+// round lane (I, J) owns the 2 x 2 block (rows of pair I) x (columns of pair J) of G and rows {2I, 2I+1} x (columns of
+// pair J) of V, reads them together with the two diagonal blocks that define the rotations of pair I and pair J
+// (recomputed per lane from the same LDS data, so bitwise the same in every lane -- nothing is broadcast), applies
+// G' = J' G J, V' = V J and writes its block back: all reads of a round precede all writes in program order, and the
+// blocks of a round are disjoint. The two rotation chains of a lane are independent instruction streams.
+// On exit diag(G) holds the eigenvalues, the columns of V the eigenvectors (G_in = V diag V'). V must hold the
+// identity (or the basis to be rotated) on entry. Call with the 64 lanes of one wavefront; returns the sweep count.
+__device__ __forceinline__ int jacobi16_wave(double (*G)[17], double (*V)[17]) {
+    const int lane = threadIdx.x & 63, I = lane >> 3, J = lane & 7;
+    const int r0 = 2 * I, c0 = 2 * J;
+    {   // symmetrise (static 2 x 2 tile per lane)
+        const double s00 = 0.5 * (G[r0][c0] + G[c0][r0]), s01 = 0.5 * (G[r0][c0 + 1] + G[c0 + 1][r0]);
+        const double s10 = 0.5 * (G[r0 + 1][c0] + G[c0][r0 + 1]), s11 = 0.5 * (G[r0 + 1][c0 + 1] + G[c0 + 1][r0 + 1]);
+        wave_lds_sync();
+        G[r0][c0] = s00; G[r0][c0 + 1] = s01; G[r0 + 1][c0] = s10; G[r0 + 1][c0 + 1] = s11;
+        wave_lds_sync();
     }
-    __syncthreads();
-    double (*Gc)[17] = G[mid], (*Gn)[17] = Gb[mid], (*Vc)[17] = V[mid], (*Vn)[17] = Vb[mid];
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        const double apq0 = Gc[a][b];
-        const int need = (a < b && apq0 * apq0 > 1.0e-34 * fabs(Gc[a][a] * Gc[b][b]) && fabs(apq0) > 1.0e-300) ? 1 : 0;
-        if (!__syncthreads_or(need)) break;
+    int sweep = 0;
+    for (; sweep < 30; ++sweep) {
+        int need = 0;   // an off-diagonal entry above the rotation threshold somewhere in the upper triangle?
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int a = r0 + (e >> 1), b = c0 + (e & 1);
+            const double apq = G[a][b];
+            if (a < b && apq * apq > CP_JACOBI_TOL2 * fabs(G[a][a] * G[b][b]) && fabs(apq) > 1.0e-300) need = 1;
+        }
+        if (!__any(need)) break;
+        int xI = I, yI = (15 - I) % 15, xJ = J, yJ = (15 - J) % 15;   // (rd + k) % 15 and (rd - k + 15) % 15 at rd = 0
         for (int rd = 0; rd < 15; ++rd) {
-            // partner of an index in round rd: (15, rd) and ((rd + k) % 15, (rd - k) % 15), k = 1..7
-            const int pa = (a == 15) ? rd : ((a == rd) ? 15 : (2 * rd - a + 15) % 15);
-            const int pb = (b == 15) ? rd : ((b == rd) ? 15 : (2 * rd - b + 15) % 15);
-            if (a == 0) {   // rotation seen from index b: new(b) = c x(b) + s x(partner), s negated for the lower index
-                const int p = min(b, pb), q = max(b, pb);
-                double c, sn;
-                jacobi_rot(Gc[p][p], Gc[q][q], Gc[p][q], c, sn);
-                cs[mid][b][0] = c;
-                cs[mid][b][1] = (b == p) ? -sn : sn;
-            }
-            __syncthreads();
-            const double ca = cs[mid][a][0], sa = cs[mid][a][1], cb = cs[mid][b][0], sb = cs[mid][b][1];
-            const double t_ab = cb * Gc[a][b] + sb * Gc[a][pb];       // column transform, rows a and partner(a)
-            const double t_pb = cb * Gc[pa][b] + sb * Gc[pa][pb];
-            Gn[a][b] = ca * t_ab + sa * t_pb;                         // row transform
-            Vn[a][b] = cb * Vc[a][b] + sb * Vc[a][pb];
-            __syncthreads();
-            { double (*tmp)[17] = Gc; Gc = Gn; Gn = tmp; }
-            { double (*tmp)[17] = Vc; Vc = Vn; Vn = tmp; }
+            // pair I = (p, q), pair J = (r, u): (rd, 15) for k = 0 and the two residues above for k = 1..7, lower first
+            const int p = (I == 0) ? rd : min(xI, yI), q = (I == 0) ? 15 : max(xI, yI);
+            const int r = (J == 0) ? rd : min(xJ, yJ), u = (J == 0) ? 15 : max(xJ, yJ);
+            xI = (xI == 14) ? 0 : xI + 1; yI = (yI == 14) ? 0 : yI + 1;
+            xJ = (xJ == 14) ? 0 : xJ + 1; yJ = (yJ == 14) ? 0 : yJ + 1;
+            const double gpp = G[p][p], gqq = G[q][q], gpq = G[p][q];
+            const double grr = G[r][r], guu = G[u][u], gru = G[r][u];
+            const double b00 = G[p][r], b01 = G[p][u], b10 = G[q][r], b11 = G[q][u];
+            const double v00 = V[r0][r], v01 = V[r0][u], v10 = V[r0 + 1][r], v11 = V[r0 + 1][u];
+            double cI, sI, cJ, sJ;
+            jacobi_rot(gpp, gqq, gpq, cI, sI);
+            jacobi_rot(grr, guu, gru, cJ, sJ);
+            // columns (pair J): x_r' = c x_r - s x_u, x_u' = s x_r + c x_u; then rows (pair I) likewise
+            const double t00 = cJ * b00 - sJ * b01, t01 = sJ * b00 + cJ * b01;
+            const double t10 = cJ * b10 - sJ * b11, t11 = sJ * b10 + cJ * b11;
+            double n00 = cI * t00 - sI * t10, n01 = cI * t01 - sI * t11;
+            double n10 = sI * t00 + cI * t10, n11 = sI * t01 + cI * t11;
+            if (I == J && sI != 0.0) { n01 = 0.0; n10 = 0.0; }   // the annihilated entry, exactly
+            wave_lds_sync();
+            G[p][r] = n00; G[p][u] = n01; G[q][r] = n10; G[q][u] = n11;
+            V[r0][r] = cJ * v00 - sJ * v01; V[r0][u] = sJ * v00 + cJ * v01;
+            V[r0 + 1][r] = cJ * v10 - sJ * v11; V[r0 + 1][u] = sJ * v10 + cJ * v11;
+            wave_lds_sync();
         }
     }
-    if (Gc != G[mid]) {     // an odd number of rounds in total (uniform: both matrices march together): copy back
-        G[mid][a][b] = Gc[a][b];
-        V[mid][a][b] = Vc[a][b];
+    return sweep;
+}
+
+// B*L is exactly mean-free over the images, so (1,..,1) is a null vector of its Gram matrix. Rounding would turn that
+// zero into sqrt(eps)*s_max; the matrix is restricted to the orthogonal complement instead (Helmert basis
+// q_j = (1,..,1,-j,0,..)/sqrt(j(j+1)), j = 1..K-1) before the eigensolve: out = Q' Gin Q, padded with zeros.
+// Two phases of <= 17 terms per thread: helmert_rows (T = Gin Q), a workgroup barrier, helmert_cols (out = Q' T).
+// Called by the 256 threads (a, b) = (t >> 4, t & 15) of a matrix.
+__device__ __forceinline__ void helmert_rows(const double (*Gin)[17], double (*T)[17], int K, int a, int b) {
+    double row = 0.0;
+    if (b < K - 1) {
+        const double nb = 1.0 / sqrt((double)(b + 1) * (b + 2));
+        for (int j = 0; j <= b + 1; ++j) {
+            const double qb = (j <= b) ? nb : -(double)(b + 1) * nb;
+            row += Gin[a][j] * qb;
+        }
     }
-    __syncthreads();
+    T[a][b] = row;
+}
+__device__ __forceinline__ void helmert_cols(const double (*T)[17], double (*out)[17], int K, int a, int b) {
+    double acc = 0.0;
+    if (a < K - 1 && b < K - 1) {
+        const double na = 1.0 / sqrt((double)(a + 1) * (a + 2));
+        for (int i = 0; i <= a + 1; ++i) {
+            const double qa = (i <= a) ? na : -(double)(a + 1) * na;
+            acc += qa * T[i][b];
+        }
+    }
+    out[a][b] = acc;
+}
+
+// Conjugate prox of the nuclear-norm constraint on the singular values (NNE/nuclear_norm_constraint.m:72-76 with
+// NNE/l1ball_projection.m:23-68), by the first 16 lanes of ONE wavefront (lane i = singular value i; call with the
+// whole wavefront, no workgroup barrier inside): S_i = sqrt(max(G_ii, 0)), z = S / mu_, P = projection of z onto the
+// unit l1-ball (sort by rank counting, running sums in the serial order of the .m file), d_i = mu_ P_i / S_i -> dvec.
+// res[0] = max_i (S_i - mu_ P_i) (largest singular value of the prox), res[1] = max_i S_i. zv, zs: LDS scratch of 16.
+__device__ __forceinline__ void l1ball_scale16(const double (*G)[17], int K, double mu_, double *zv, double *zs,
+                                               double *dvec, double *res, double *__restrict__ sv_out) {
+    const int i = threadIdx.x & 63;
+    const bool on = i < K;
+    const double Si = on ? sqrt(fmax(G[i & 15][i & 15], 0.0)) : 0.0;
+    const double zi = Si / mu_;
+    if (i < 16) { zv[i] = on ? zi : 0.0; zs[i] = 0.0; }
+    if (on) sv_out[i] = Si;
+    wave_lds_sync();
+    double sumz = 0.0;
+    int rank = 0;
+    for (int j = 0; j < K; ++j) {
+        const double zj = zv[j];
+        sumz += zj;
+        rank += (zj > zi || (zj == zi && j < i)) ? 1 : 0;
+    }
+    const bool inside = (sumz <= 1.0);                    // NNE/l1ball_projection.m:28
+    if (on) zs[rank] = zi;                                // descending
+    wave_lds_sync();
+    double cum = 0.0;
+    for (int j = 0; j < 16; ++j) cum += (j <= i) ? zs[j] : 0.0;
+    const double th = (cum - 1.0) / (double)(i + 1);
+    const bool okth = on && (zs[i & 15] - th > 0.0);
+    const unsigned long long mk = __ballot(okth);
+    const int last = mk ? 63 - __clzll((long long)mk) : 0;   // the largest such index wins (monotone)
+    const double theta = (inside || !mk) ? 0.0 : __shfl(th, last);
+    const double Pi = inside ? zi : fmax(zi - theta, 0.0);   // :65-66 (sign(z) = +)
+    const double sp = Si - mu_ * Pi;                         // nuclear_norm_constraint.m:76
+    if (i < 16) {
+        dvec[i] = (on && Si > 0.0) ? (mu_ * Pi) / Si : 0.0;
+        zv[i] = on ? sp : 0.0;
+        zs[i] = Si;
+    }
+    wave_lds_sync();
+    if (i == 0) {
+        double spmax = 0.0, smax = 0.0;
+        for (int j = 0; j < 16; ++j) { spmax = fmax(spmax, zv[j]); smax = fmax(smax, zs[j]); }
+        res[0] = spmax; res[1] = smax;
+    }
 }
 
 // Eigen-decomposition of NM (1 or 2) symmetric 16 x 16 matrices GG[mid] on NM*256 live threads, optionally warm-started:
 // the matrices of consecutive CP iterations differ little, so G' = V0' G V0 with the previous eigenvectors V0 is almost
 // diagonal and needs 2-3 sweeps instead of ~8; the eigenvectors in the original basis are V0 * V. On exit diag(GG[mid])
 // holds the eigenvalues, VV[mid] the eigenvectors; they are also stored to vwarm (if given) for the next call.
-// V0, Tm, VB: LDS scratch matrices; cs: rotations of a round. Ends with a barrier.
+// V0, Tm: LDS scratch matrices. The Jacobi iteration itself runs on one wavefront per matrix (jacobi16_wave); the
+// others wait at the barrier that follows. Ends with a barrier.
+template <int NM>
 __device__ __forceinline__ void eig16_warm(double (*GG)[16][17], double (*VV)[16][17], double (*V0)[16][17],
-                                           double (*Tm)[16][17], double (*VB)[16][17], double (*cs)[16][2],
-                                           double *__restrict__ vwarm, int warm) {
+                                           double (*Tm)[16][17], double *__restrict__ vwarm, int warm) {
     const int t = threadIdx.x, mid = t >> 8, tl = t & 255, r = tl >> 4, c = tl & 15;
     const bool w = warm && vwarm;
     VV[mid][r][c] = (r == c) ? 1.0 : 0.0;
@@ -266,7 +375,16 @@ __device__ __forceinline__ void eig16_warm(double (*GG)[16][17], double (*VV)[16
         GG[mid][r][c] = acc;
     }
     __syncthreads();
-    jacobi16_pair(GG, VV, Tm, VB, cs);
+    EPROF(3);
+    if ((t >> 6) < NM) {   // one wavefront per matrix (wavefronts 0 and 1: different SIMDs -- the iteration is issue-bound), no workgroup barrier inside
+        const int sw = jacobi16_wave(GG[t >> 6], VV[t >> 6]);
+        (void)sw;
+#ifdef CP_EPROF
+        if ((t & 63) == 0) g_eprof[20 + (t >> 6)] = sw;
+#endif
+    }
+    __syncthreads();
+    EPROF(4);
     if (w) {   // eigenvectors in the original basis: V0 * V
         double acc = 0.0;
         for (int i = 0; i < 16; ++i) acc += V0[mid][r][i] * VV[mid][i][c];
@@ -280,52 +398,21 @@ __device__ __forceinline__ void eig16_warm(double (*GG)[16][17], double (*VV)[16
 // ---- dual-side finalisation: W for y3, F* values, primal row rp, stop rule ------------------------
 __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_eig(EigArgs A, const double *__restrict__ part, CpCtrl *ctrl,
                                                            double *__restrict__ Wout, double *hist_p, double *hist_d) {
-    __shared__ double GG[1][16][17], VV[1][16][17], V0[1][16][17], Tm[1][16][17], VB[1][16][17], cs[1][16][2], sc[CP_NSCAL],
+    __shared__ double GG[1][16][17], VV[1][16][17], V0[1][16][17], Tm[1][16][17], sc[CP_NSCAL],
         dvec[16], stage[CP_RED_THREADS];
     double (*G)[17] = GG[0], (*V)[17] = VV[0];
-    if (ctrl->stop) return;
     const int t = threadIdx.x;
-    __shared__ double S[16], z[16], zs[16];   // dynamically indexed below: LDS, not scratch
+    __shared__ double z[16], zs[16], res[2];
+    const int stopped = ctrl->stop;   // requested together with the reduction's loads; see k_mf_efused
+    const double nu = ctrl->nu;
     reduce_partials(part, A.nblk, G, sc, stage);
+    if (stopped) return;
     if (t >= 256) return;        // the eigensolve needs 256 threads; ended waves do not take part in barriers
-    eig16_warm(GG, VV, V0, Tm, VB, cs, A.vwarm, A.warm);
+    eig16_warm<1>(GG, VV, V0, Tm, A.vwarm, A.warm);
+    if (t < 64) l1ball_scale16(G, A.K, nu * A.sigma, z, zs, dvec, res, ctrl->sv);   // NNE/nuclear_norm_constraint.m:72
+    __syncthreads();
     if (t == 0) {
-        const int K = A.K;
-        const double nu = ctrl->nu;
-        const double mu_ = nu * A.sigma;                  // NNE/nuclear_norm_constraint.m:72
-        double sumz = 0.0;
-        for (int i = 0; i < K; ++i) {
-            S[i] = sqrt(fmax(G[i][i], 0.0));
-            z[i] = S[i] / mu_;
-            zs[i] = z[i];
-            sumz += z[i];
-            ctrl->sv[i] = S[i];
-        }
-        double theta = 0.0;
-        const bool inside = (sumz <= 1.0);                // NNE/l1ball_projection.m:28
-        if (!inside) {
-            for (int i = 1; i < K; ++i) {                 // sort descending
-                const double v = zs[i];
-                int j = i - 1;
-                while (j >= 0 && zs[j] < v) { zs[j + 1] = zs[j]; --j; }
-                zs[j + 1] = v;
-            }
-            double cum = 0.0;
-            for (int i = 0; i < K; ++i) {
-                cum += zs[i];
-                const double th = (cum - 1.0) / (double)(i + 1);
-                if (zs[i] - th > 0.0) theta = th;         // largest such i wins (monotone)
-            }
-        }
-        double spmax = 0.0, smax = 0.0;
-        for (int i = 0; i < 16; ++i) dvec[i] = 0.0;
-        for (int i = 0; i < K; ++i) {
-            const double Pi = inside ? z[i] : fmax(z[i] - theta, 0.0);   // :65-66 (sign(z) = +)
-            const double sp = S[i] - mu_ * Pi;                           // :76
-            dvec[i] = (S[i] > 0.0) ? (mu_ * Pi) / S[i] : 0.0;
-            spmax = fmax(spmax, sp);
-            smax = fmax(smax, S[i]);
-        }
+        const double spmax = res[0], smax = res[1];
         if (A.rd >= 0) {
             double *hd = hist_d + (size_t)A.rd * CP_HCOLS_MF;
             hd[1] = sc[DS_F1S];                                                    // NNE/SAD.m:83
@@ -374,37 +461,23 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_eig(EigArgs A, const doub
 // ---- primal-side finalisation: offsets c, feasibility of B*L, G* measures, dual row rd ------------
 __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_fin(EigArgs A, const double *__restrict__ part, CpCtrl *ctrl,
                                                            double *hist_p, double *hist_d) {
-    __shared__ double GG[1][16][17], VV[1][16][17], V0[1][16][17], Tm[1][16][17], VB[1][16][17], cs[1][16][2], sc[CP_NSCAL],
+    __shared__ double GG[1][16][17], VV[1][16][17], V0[1][16][17], Tm[1][16][17], sc[CP_NSCAL],
         stage[CP_RED_THREADS];
     double (*G)[17] = GG[0];
-    if (ctrl->stop) return;
+    const int stopped = ctrl->stop;
+    const double nu = ctrl->nu;
     reduce_partials(part, A.nblk, G, sc, stage);
-    {
-        // B*L is exactly mean-free over the images, so (1,..,1) is a null vector of its Gram matrix. Rounding would
-        // turn that zero into sqrt(eps)*s_max; restrict the matrix to the orthogonal complement instead
-        // (Helmert basis q_j = (1,..,1,-j,0,..)/sqrt(j(j+1)), j = 1..K-1) before the eigensolve.
-        const int t = threadIdx.x, a = (t >> 4) & 15, bq = t & 15, K = A.K;
-        double acc = 0.0;
-        if (t < 256 && a < K - 1 && bq < K - 1) {
-            const double na = 1.0 / sqrt((double)(a + 1) * (a + 2)), nb = 1.0 / sqrt((double)(bq + 1) * (bq + 2));
-            for (int i = 0; i <= a + 1; ++i) {
-                const double qa = (i <= a) ? na : -(double)(a + 1) * na;
-                double row = 0.0;
-                for (int j = 0; j <= bq + 1; ++j) {
-                    const double qb = (j <= bq) ? nb : -(double)(bq + 1) * nb;
-                    row += G[i][j] * qb;
-                }
-                acc += qa * row;
-            }
-        }
+    if (stopped) return;
+    {   // Gram(B*L) restricted to the complement of (1,..,1) (see helmert_rows)
+        const int t = threadIdx.x;
         if (t >= 256) return;    // the eigensolve needs 256 threads; ended waves do not take part in barriers
+        helmert_rows(G, Tm[0], A.K, t >> 4, t & 15);
         __syncthreads();
-        G[a][bq] = acc;
+        helmert_cols(Tm[0], G, A.K, t >> 4, t & 15);
         __syncthreads();
     }
-    eig16_warm(GG, VV, V0, Tm, VB, cs, A.vwarm, A.warm);
+    eig16_warm<1>(GG, VV, V0, Tm, A.vwarm, A.warm);
     if (threadIdx.x == 0) {
-        const double nu = ctrl->nu;
         double sumS = 0.0;
         for (int i = 0; i < A.K; ++i) ctrl->svL[i] = 0.0;
         for (int i = 0; i < A.K - 1; ++i) {
