@@ -87,15 +87,18 @@ __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParam
     __shared__ double tiles[NWV * 2 * 16 * CP_TS];
     __shared__ double red[NWV * CP_NSCAL];
     __shared__ double Wl[CP_KMAX * CP_KMAX];
-    if (ctrl->stop) return;
+    // the control words and W are requested together: one global round trip before the first tile instead of three
+    // (it is a visible part of the 40 us a launch takes on the coarse pyramid levels)
+    const int stopped = ctrl->stop;
+    const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *tileA = tiles + wave * 2 * 16 * CP_TS, *tileB = tileA + 16 * CP_TS;
     const int K = P.K, m = P.m;
     const size_t fs = (size_t)P.fs;
     const bool linear = LINEAR;
     stage_W(W, Wl);
+    if (stopped) return;
     __syncthreads();
-    const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
     const double sigma = P.sigma, tau = P.tau, theta = P.theta, inv_sigma = 1.0 / P.sigma;
     const S *y3in = pin + 5 * (size_t)K * fs;
     S *y3out = pout + 5 * (size_t)K * fs;
