@@ -801,30 +801,34 @@ static void launch_fused(cp_engine *h, const MfParams &P, const double *xp, doub
 
 // First stage of the reduction of the fused kernel's partial rows: output row r = fixed-order sum (slots < CP_NSUM and
 // the Gram entries) / maximum (slots CP_NSUM..CP_NSCAL-1) of input rows [r*CP_S1_GROUP, (r+1)*CP_S1_GROUP).
-// blockIdx.y selects a chunk of 256 columns; a thread owns one column and keeps 16 loads in flight (the kernel is a few
-// dependent round trips long: with one workgroup per row group walking its three column chunks in turn it took 13 us).
-__global__ __launch_bounds__(256) void k_mf_reduce_stage1(int nrows, const double *__restrict__ part, double *__restrict__ out) {
-    const int r0 = blockIdx.x * CP_S1_GROUP, r1 = min(nrows, r0 + CP_S1_GROUP);
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= CP_PSTRIDE) return;
+// blockIdx.y selects a chunk of 256 columns; 1024 threads = 4 row quarters x 256 columns, a thread sums 16 rows of one
+// column (row index clamped, loads unconditional), the quarters are combined in fixed order through LDS. The kernel is
+// a few dependent round trips long: many waves in flight matter, not the work per thread (17 MB of partial rows at
+// 4096 workgroups; one workgroup per row group walking its three column chunks in turn took 18 us).
+__global__ __launch_bounds__(1024) void k_mf_reduce_stage1(int nrows, const double *__restrict__ part, double *__restrict__ out) {
+    __shared__ double stage[4][256];
+    const int tx = threadIdx.x & 255, sub = threadIdx.x >> 8;
+    const int r1 = min(nrows, (int)(blockIdx.x + 1) * CP_S1_GROUP);
+    const int r0 = blockIdx.x * CP_S1_GROUP + sub * (CP_S1_GROUP / 4);
+    const int c = min((int)blockIdx.y * 256 + tx, CP_PSTRIDE - 1);
     const bool is_max = (c >= CP_NSUM && c < CP_NSCAL);
-    double a[16];
+    double a[CP_S1_GROUP / 4];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) a[u] = is_max ? -1.0e300 : 0.0;
-    for (int r = r0; r < r1; r += 16) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (r + u < r1) {   // uniform
-                const double o = part[(size_t)(r + u) * CP_PSTRIDE + c];
-                a[u] = is_max ? fmax(a[u], o) : a[u] + o;
-            }
-        }
+    for (int u = 0; u < CP_S1_GROUP / 4; ++u) {
+        const double o = part[(size_t)min(r0 + u, nrows - 1) * CP_PSTRIDE + c];
+        a[u] = (r0 + u < r1) ? o : (is_max ? -1.0e300 : 0.0);
     }
 #pragma unroll
-    for (int w = 8; w >= 1; w >>= 1)
+    for (int w = CP_S1_GROUP / 8; w >= 1; w >>= 1)
 #pragma unroll
         for (int u = 0; u < w; ++u) a[u] = is_max ? fmax(a[u], a[u + w]) : a[u] + a[u + w];
-    out[(size_t)blockIdx.x * CP_PSTRIDE + c] = a[0];
+    stage[sub][tx] = a[0];
+    __syncthreads();
+    if (sub == 0 && (int)blockIdx.y * 256 + tx < CP_PSTRIDE) {
+        const double v = is_max ? fmax(fmax(stage[0][tx], stage[1][tx]), fmax(stage[2][tx], stage[3][tx]))
+                                : (stage[0][tx] + stage[1][tx]) + (stage[2][tx] + stage[3][tx]);
+        out[(size_t)blockIdx.x * CP_PSTRIDE + c] = v;
+    }
 }
 
 // partial rows of the last k_mf_fused_tv launch as the single-workgroup kernels read them (after stage 1 if needed:
@@ -832,7 +836,7 @@ __global__ __launch_bounds__(256) void k_mf_reduce_stage1(int nrows, const doubl
 static const double *fused_partials(cp_engine *h, int *rows) {
     if (h->nblk_fused <= 128) { *rows = h->nblk_fused; return h->part; }
     const int r2 = (h->nblk_fused + CP_S1_GROUP - 1) / CP_S1_GROUP;
-    hipLaunchKernelGGL(k_mf_reduce_stage1, dim3(r2, (CP_PSTRIDE + 255) / 256), dim3(256), 0, h->stream, h->nblk_fused,
+    hipLaunchKernelGGL(k_mf_reduce_stage1, dim3(r2, (CP_PSTRIDE + 255) / 256), dim3(1024), 0, h->stream, h->nblk_fused,
                        h->part, h->part2);
     *rows = r2;
     return h->part2;
