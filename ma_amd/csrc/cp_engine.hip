@@ -755,51 +755,7 @@ static EigArgs eig_args(const cp_engine *h, const MfParams &P, int rp, int rd, i
     return A;
 }
 
-// iterations n = n0+1 .. n0+count of PDO/chambolle_pock.m:156-179 (state parity follows n)
-static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int check, double tol) {
-    CpCtrl *ctrl = (CpCtrl *)h->ctrl;
-    for (int n = n0 + 1; n <= n0 + count; ++n) {
-        const int cur = (n - 1) & 1, nxt = n & 1;
-        CPCHK(timer_begin(h, T_DUAL));
-        launch_mf_dual<0>(h, P, h->X[cur], h->X[nxt], h->P[cur], h->P[nxt], h->W[cur], cur, nxt);
-        CPCHK(timer_end(h, T_DUAL));
-        CPCHK(timer_begin(h, T_EIG));
-        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream,
-                           with_warm(eig_args(h, P, n - 1, n, check, 0, 0, tol), h, n, 0), h->part, ctrl, h->W[nxt], h->hist_p,
-                           h->hist_d);
-        CPCHK(timer_end(h, T_EIG));
-        CPCHK(timer_begin(h, T_PRIMAL));
-        launch_mf_primal<0>(h, P, h->X[cur], h->X[nxt], h->P[nxt], h->W[nxt], cur);
-        CPCHK(timer_end(h, T_PRIMAL));
-        CPCHK(timer_begin(h, T_FIN));
-        hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream,
-                           with_warm(eig_args(h, P, n, n, 0, 1, nxt, tol), h, n, 1), h->part, ctrl, h->hist_p, h->hist_d);
-        CPCHK(timer_end(h, T_FIN));
-    }
-    HIPCHK(hipGetLastError());
-    return CP_OK;
-}
-
-// one launch of k_mf_fused_tv: x_{n-1} in xp, x_n written to xc; y_n in pc, y_{n+1} written to pn
-template <typename S, int TW, int NT = CP_BLOCK>
-static void launch_fused_tw(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
-                            const double *W) {
-    auto kern = (h->d.bc == CP_BC_LINEAR)
-                    ? (h->K == CP_KMAX ? k_mf_fused_tv<S, true, true, TW, NT> : k_mf_fused_tv<S, true, false, TW, NT>)
-                    : (h->K == CP_KMAX ? k_mf_fused_tv<S, false, true, TW, NT> : k_mf_fused_tv<S, false, false, TW, NT>);
-    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(NT), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
-                       (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
-}
-static void launch_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
-                         const double *W) {
-    if (h->fused_nt == 512 && !h->fp32) launch_fused_tw<double, 2, 512>(h, P, xp, xc, pc, pn, W);
-    else if (h->fp32) launch_fused_tw<float, 1>(h, P, xp, xc, pc, pn, W);   // the tile-width knob is an fp64 tuning aid
-    else if (h->fused_tw == 1) launch_fused_tw<double, 1>(h, P, xp, xc, pc, pn, W);
-    else if (h->fused_tw == 2) launch_fused_tw<double, 2>(h, P, xp, xc, pc, pn, W);
-    else launch_fused_tw<double, 4>(h, P, xp, xc, pc, pn, W);
-}
-
-// First stage of the reduction of the fused kernel's partial rows: output row r = fixed-order sum (slots < CP_NSUM and
+// First stage of the reduction of a field kernel's partial rows: output row r = fixed-order sum (slots < CP_NSUM and
 // the Gram entries) / maximum (slots CP_NSUM..CP_NSCAL-1) of input rows [r*CP_S1_GROUP, (r+1)*CP_S1_GROUP).
 // blockIdx.y selects a chunk of 256 columns; 1024 threads = 4 row quarters x 256 columns, a thread sums 16 rows of one
 // column (row index clamped, loads unconditional), the quarters are combined in fixed order through LDS. The kernel is
@@ -831,17 +787,63 @@ __global__ __launch_bounds__(1024) void k_mf_reduce_stage1(int nrows, const doub
     }
 }
 
-// partial rows of the last k_mf_fused_tv launch as the single-workgroup kernels read them (after stage 1 if needed:
-// k_mf_efused alone reads about 18 rows per microsecond)
-static const double *fused_partials(cp_engine *h, int *rows) {
-    if (h->nblk_fused <= 128) { *rows = h->nblk_fused; return h->part; }
-    const int r2 = (h->nblk_fused + CP_S1_GROUP - 1) / CP_S1_GROUP;
-    hipLaunchKernelGGL(k_mf_reduce_stage1, dim3(r2, (CP_PSTRIDE + 255) / 256), dim3(1024), 0, h->stream, h->nblk_fused,
-                       h->part, h->part2);
+// partial rows of the last field kernel as the single-workgroup kernels read them (after stage 1 if there are more than
+// 128: a single workgroup reads about 18 rows per microsecond)
+static const double *staged_partials(cp_engine *h, int nrows, int *rows) {
+    if (nrows <= 128) { *rows = nrows; return h->part; }
+    const int r2 = (nrows + CP_S1_GROUP - 1) / CP_S1_GROUP;
+    hipLaunchKernelGGL(k_mf_reduce_stage1, dim3(r2, (CP_PSTRIDE + 255) / 256), dim3(1024), 0, h->stream, nrows, h->part,
+                       h->part2);
     *rows = r2;
     return h->part2;
 }
+static const double *fused_partials(cp_engine *h, int *rows) { return staged_partials(h, h->nblk_fused, rows); }
 
+// iterations n = n0+1 .. n0+count of PDO/chambolle_pock.m:156-179 (state parity follows n)
+static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int check, double tol) {
+    CpCtrl *ctrl = (CpCtrl *)h->ctrl;
+    for (int n = n0 + 1; n <= n0 + count; ++n) {
+        const int cur = (n - 1) & 1, nxt = n & 1;
+        CPCHK(timer_begin(h, T_DUAL));
+        launch_mf_dual<0>(h, P, h->X[cur], h->X[nxt], h->P[cur], h->P[nxt], h->W[cur], cur, nxt);
+        CPCHK(timer_end(h, T_DUAL));
+        CPCHK(timer_begin(h, T_EIG));
+        EigArgs Ae = with_warm(eig_args(h, P, n - 1, n, check, 0, 0, tol), h, n, 0);
+        const double *rows_e = staged_partials(h, h->nblk, &Ae.nblk);
+        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, Ae, rows_e, ctrl, h->W[nxt], h->hist_p,
+                           h->hist_d);
+        CPCHK(timer_end(h, T_EIG));
+        CPCHK(timer_begin(h, T_PRIMAL));
+        launch_mf_primal<0>(h, P, h->X[cur], h->X[nxt], h->P[nxt], h->W[nxt], cur);
+        CPCHK(timer_end(h, T_PRIMAL));
+        CPCHK(timer_begin(h, T_FIN));
+        EigArgs Af = with_warm(eig_args(h, P, n, n, 0, 1, nxt, tol), h, n, 1);
+        const double *rows_f = staged_partials(h, h->nblk, &Af.nblk);
+        hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, Af, rows_f, ctrl, h->hist_p, h->hist_d);
+        CPCHK(timer_end(h, T_FIN));
+    }
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+
+// one launch of k_mf_fused_tv: x_{n-1} in xp, x_n written to xc; y_n in pc, y_{n+1} written to pn
+template <typename S, int TW, int NT = CP_BLOCK>
+static void launch_fused_tw(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
+                            const double *W) {
+    auto kern = (h->d.bc == CP_BC_LINEAR)
+                    ? (h->K == CP_KMAX ? k_mf_fused_tv<S, true, true, TW, NT> : k_mf_fused_tv<S, true, false, TW, NT>)
+                    : (h->K == CP_KMAX ? k_mf_fused_tv<S, false, true, TW, NT> : k_mf_fused_tv<S, false, false, TW, NT>);
+    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(NT), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
+                       (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
+}
+static void launch_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
+                         const double *W) {
+    if (h->fused_nt == 512 && !h->fp32) launch_fused_tw<double, 2, 512>(h, P, xp, xc, pc, pn, W);
+    else if (h->fp32) launch_fused_tw<float, 1>(h, P, xp, xc, pc, pn, W);   // the tile-width knob is an fp64 tuning aid
+    else if (h->fused_tw == 1) launch_fused_tw<double, 1>(h, P, xp, xc, pc, pn, W);
+    else if (h->fused_tw == 2) launch_fused_tw<double, 2>(h, P, xp, xc, pc, pn, W);
+    else launch_fused_tw<double, 4>(h, P, xp, xc, pc, pn, W);
+}
 
 // ---- fused NN-TV path: F_0 = dual step 1 alone, then one k_mf_fused_tv + k_mf_efused per iteration -------------
 static int mf_fused_start(cp_engine *h, const MfParams &P, double tol) {
