@@ -64,6 +64,10 @@ class _StdoutToStderr:
 
 
 def _init_process_group(dist, torch, backend, local_rank):
+    # a single process without a launcher (CP_FORCE_SLAB_PATH=1 on one GPU): a one-rank group on the loopback address
+    for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"),
+                     ("MASTER_PORT", "29533")):
+        os.environ.setdefault(key, val)
     with _StdoutToStderr():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
