@@ -147,6 +147,72 @@ def test_extreme_shapes(reg, bc, m, n, k):
     assert _rel(x, xr) < TOL and _rel(y, yr) < TOL
 
 
+@pytest.mark.parametrize("case,k", [("identical_frames", 6), ("zero_dual", 4), ("nu_small", 5), ("nu_large", 5),
+                                    ("two_groups", 16)])
+def test_degenerate_spectra(case, k):
+    """Gram matrices the K x K eigensolve finds hard: repeated eigenvalues (identical frames: rank-1 y3 / B*L = 0; two groups
+    of identical frames: rank 2 with K = 16), an exactly zero matrix (y0 = 0 and L0 = 0 in the first row), every singular value
+    clipped (tiny nu) and none (huge nu: the point is inside the l1-ball, NNE/l1ball_projection.m:28). Eigenvectors are
+    not unique there, W = I - V diag(d) V' is (d is constant on an eigenspace): iterates and histories must match the oracle."""
+    from ma_amd import engine as E
+    from oracle import drivers as od
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    m, n, reg, bc = 24, 20, "tv", "neumann"
+    rng = np.random.default_rng(17 + k)
+    base = rng.random((2, m, n))
+    if case == "identical_frames":
+        imgs = np.repeat(base[:1], k, axis=0)
+    elif case == "two_groups":
+        imgs = np.stack([base[i % 2] for i in range(k)])
+    else:
+        imgs = rng.random((k, m, n))
+    u0 = 0.3 * rng.standard_normal((k, 2, n * m))
+    if case in ("identical_frames", "two_groups"):
+        u0 = np.stack([u0[i % 2] if case == "two_groups" else u0[0] for i in range(k)])
+    u0_ref = np.transpose(u0, (2, 1, 0))
+    omega = [0.0, float(m), 0.0, float(n)]
+    h = (1.0, 1.0)
+    A, b, T_u, gs = od.mf_nn_problem([imgs[i] for i in range(k)], u0_ref, h, omega, reg, bc)
+    mu, tau, sigma = 0.2, 0.2, 0.2
+    nu = {"nu_small": 1e-6, "nu_large": 1e6}.get(case, 0.5 * k)
+    kmn = k * m * n
+    zero = case == "zero_dual"
+    x0 = np.concatenate([u0.reshape(-1), (0.0 if zero else 0.5) * T_u.reshape(-1, order="F")])
+    y0 = np.zeros(6 * kmn) if zero else 0.01 * rng.standard_normal(6 * kmn)
+    if case in ("identical_frames", "two_groups"):      # keep the dual in the same symmetry class
+        yb = 0.01 * rng.standard_normal((6, 2, m * n))
+        y0 = np.concatenate([np.concatenate([yb[0, i % 2] for i in range(k)]),
+                             np.concatenate([np.concatenate([yb[1 + c, i % 2] for c in range(4)]) for i in range(k)]),
+                             np.concatenate([yb[5, i % 2] for i in range(k)])])
+        if case == "identical_frames":
+            y0 = np.concatenate([np.tile(yb[0, 0], k), np.tile(np.concatenate([yb[1 + c, 0] for c in range(4)]), k),
+                                 np.tile(yb[5, 0], k)])
+    Fh = lambda y, c, nargout: od.mf_nn_F(y, b, k, h, mu, nu, sigma, c, nargout, reg)
+    Gh = lambda x, c, nargout: od.mf_nn_G(x, (m, n, k), c, nargout)
+    iters = 14
+    xr, yr, phr, dhr = cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, sigma, iters, 1e-3)
+    eng = E.Engine(E.MODEL_MF_NN_TV, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu)
+    eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+    eng.set_primal(x0)
+    eng.linearize()
+    eng.set_dual(y0)
+    eng.set_nu(nu)
+    eng.solve(1.0, tau, sigma, iters, 1e-3)
+    x, y = eng.primal(), eng.dual()
+    ph, dh = eng.history()
+    eng.close()
+    assert np.isfinite(x).all() and np.isfinite(y).all() and np.isfinite(ph).all() and np.isfinite(dh).all()
+    assert ph.shape == phr.shape
+    scale = max(np.linalg.norm(yr), 1e-300)
+    assert _rel(x, xr) < TOL
+    assert np.linalg.norm(y - yr) / scale < 1e-9 or np.linalg.norm(y - yr) < 1e-12
+    np.testing.assert_allclose(ph[:, :5], phr[:, :5], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(dh[:, :5], dhr[:, :5], rtol=1e-9, atol=1e-9)
+    # the constraint columns: (sum s - nu)/nu amplifies rounding by 1/nu for a tiny nu
+    np.testing.assert_allclose(ph[:, 5:], phr[:, 5:], rtol=1e-6, atol=1e-6 if case != "nu_small" else 1e-3)
+    np.testing.assert_allclose(dh[:, 5:], dhr[:, 5:], rtol=1e-6, atol=1e-8)
+
+
 def test_long_run_against_c_restatement():
     """300 iterations (warm-started eigensolves with periodic cold restarts, lazy W, predicted means) stay within the
     north_star tolerance of the C restatement"""
