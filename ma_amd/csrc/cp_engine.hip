@@ -1175,7 +1175,7 @@ static int pw_fused_iterations(cp_engine *h, const PwParams &P, int n0, int coun
         A.gt = h->gt; A.n = n; A.check_stop = check; A.hist_rows = h->hist_rows; A.tol = tol;
         A.lambda = h->d.lambda;
         if (h->time_all) CPCHK(timer_begin(h, T_FIN));
-        hipLaunchKernelGGL(k_pw_fin_fused, dim3(h->batch), dim3(PW_FIN_THREADS), 0, h->stream, A, h->part, ctrl, h->hist_p,
+        hipLaunchKernelGGL(k_pw_fin_fused, dim3(h->batch), dim3(PW_FINF_THREADS), 0, h->stream, A, h->part, ctrl, h->hist_p,
                            h->hist_d);
         if (h->time_all) CPCHK(timer_end(h, T_FIN));
     }

@@ -528,29 +528,51 @@ struct PwFusedFinArgs {
     int nblk, gt, n, check_stop, hist_rows;
     double tol, lambda;
 };
-__global__ __launch_bounds__(PW_FIN_THREADS) void k_pw_fin_fused(PwFusedFinArgs A, const double *__restrict__ part_,
-                                                                 PwCtrl *ctrl, double *hist_p_, double *hist_d_) {
-    __shared__ double stage[PW_FIN_THREADS], tot[8];
+// 1024 threads = 128 sub-groups x 8 slots, 4 unconditional loads (row clamped) in flight per thread: the kernel is a
+// chain of global round trips on one workgroup per problem (2112 partial rows at 2048^2: 25 us with 256 threads and one
+// load at a time).
+#define PW_FINF_THREADS 1024
+__global__ __launch_bounds__(PW_FINF_THREADS) void k_pw_fin_fused(PwFusedFinArgs A, const double *__restrict__ part_,
+                                                                  PwCtrl *ctrl, double *hist_p_, double *hist_d_) {
+    __shared__ double stage[PW_FINF_THREADS], stage2[64], tot[8];
     const int prob = blockIdx.x;
-    if (ctrl[prob].stop) return;
+    const int stopped = ctrl[prob].stop;
     const int t = threadIdx.x, slot = t & 7, sub = t >> 3;
+    constexpr int NSUB = PW_FINF_THREADS / 8;
     const double *part = part_ + (size_t)prob * A.nblk * PWF_PSTRIDE;
     {
         const bool live = slot < PWF_NS + PWF_NM, is_sum = slot < PWF_NS;
-        double v = 0.0;                                   // all maxima are of non-negative quantities
-        if (live)
-            for (int bI = sub; bI < A.nblk; bI += PW_FIN_THREADS / 8) {
-                const double o = part[(size_t)bI * PWF_PSTRIDE + slot];
-                v = is_sum ? v + o : fmax(v, o);
+        const int sl = live ? slot : 0;
+        double v[4] = {0.0, 0.0, 0.0, 0.0};               // all maxima are of non-negative quantities
+        for (int bI = sub; bI < A.nblk; bI += 4 * NSUB) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = bI + u * NSUB;
+                const double o = part[(size_t)min(r, A.nblk - 1) * PWF_PSTRIDE + sl];
+                const double w = is_sum ? v[u] + o : fmax(v[u], o);
+                v[u] = (r < A.nblk) ? w : v[u];
             }
-        stage[t] = v;
+        }
+        stage[t] = live ? (is_sum ? (v[0] + v[1]) + (v[2] + v[3]) : fmax(fmax(v[0], v[1]), fmax(v[2], v[3]))) : 0.0;
+    }
+    if (stopped) return;
+    __syncthreads();
+    if (t < 64) {   // 8 lanes per slot combine 16 sub-groups each, then lane 0 of the slot the 8 partial results
+        const int s8 = t & 7, grp = t >> 3;
+        const bool is_sum = s8 < PWF_NS;
+        double v = stage[(grp * 16) * 8 + s8];
+        for (int u = 1; u < 16; ++u) {
+            const double o = stage[(grp * 16 + u) * 8 + s8];
+            v = is_sum ? v + o : fmax(v, o);
+        }
+        stage2[t] = v;
     }
     __syncthreads();
     if (t < 8) {
         const bool is_sum = t < PWF_NS;
-        double v = stage[t];
-        for (int u = 1; u < PW_FIN_THREADS / 8; ++u) {
-            const double o = stage[u * 8 + t];
+        double v = stage2[t];
+        for (int u = 1; u < 8; ++u) {
+            const double o = stage2[u * 8 + t];
             v = is_sum ? v + o : fmax(v, o);
         }
         tot[t] = v;
