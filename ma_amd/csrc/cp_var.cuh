@@ -26,11 +26,23 @@ __device__ __forceinline__ void reduce_scalars(const double *__restrict__ part, 
     const int t = threadIdx.x, slot = t & 31, sub = t >> 5;
     const bool is_sum = slot < CP_NSUM;
     double v = is_sum ? 0.0 : -1.0e300;
-    if (slot < CP_NSCAL)
-        for (int bI = sub; bI < nblk; bI += 8) {
-            const double o = part[(size_t)bI * CP_PSTRIDE + slot];
-            v = is_sum ? v + o : fmax(v, o);
+    if (slot < CP_NSCAL) {
+        // 8 unconditional loads (row clamped) in flight per thread: the kernel is a chain of global round trips
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = v;
+        for (int bI = sub; bI < nblk; bI += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = bI + 8 * u;
+                const double o = part[(size_t)min(r, nblk - 1) * CP_PSTRIDE + slot];
+                const double w = is_sum ? a[u] + o : fmax(a[u], o);
+                a[u] = (r < nblk) ? w : a[u];
+            }
         }
+        v = is_sum ? ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))
+                   : fmax(fmax(fmax(a[0], a[1]), fmax(a[2], a[3])), fmax(fmax(a[4], a[5]), fmax(a[6], a[7])));
+    }
     stage[t] = v;
     __syncthreads();
     if (t < CP_NSCAL) {
