@@ -1640,7 +1640,11 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
     switch (stage) {
         case CP_STAGE_DUAL0:
             launch_mf_dual<0>(h, P, h->X[0], h->X[1], h->P[0], h->P[1], h->W[0], 0, 1);
-            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk, h->part, dev_buf);
+            {
+                int nrows_l = 0;
+                const double *rows_l = staged_partials(h, h->nblk, &nrows_l);
+                hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, nrows_l, rows_l, dev_buf);
+            }
             break;
         case CP_STAGE_EIG0: {
             EigArgs A = eig_args(h, P, -1, 1, 0, 0, 0, tol, 0, 1);
@@ -1677,7 +1681,11 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             CPCHK(timer_begin(h, T_DUAL));
             launch_mf_dual<0>(h, P, h->X[cur], h->X[nxt], h->P[cur], h->P[nxt], h->W[cur], cur, nxt);
             CPCHK(timer_end(h, T_DUAL));
-            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk, h->part, dev_buf);
+            {
+                int nrows_l = 0;
+                const double *rows_l = staged_partials(h, h->nblk, &nrows_l);
+                hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, nrows_l, rows_l, dev_buf);
+            }
             break;
         }
         case CP_STAGE_SPLIT_EIG: {
@@ -1692,7 +1700,11 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             CPCHK(timer_begin(h, T_PRIMAL));
             launch_mf_primal<0>(h, P, h->X[cur], h->X[nxt], h->P[nxt], h->W[nxt], cur);
             CPCHK(timer_end(h, T_PRIMAL));
-            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk, h->part, dev_buf);
+            {
+                int nrows_l = 0;
+                const double *rows_l = staged_partials(h, h->nblk, &nrows_l);
+                hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, nrows_l, rows_l, dev_buf);
+            }
             break;
         }
         case CP_STAGE_SPLIT_FIN: {
@@ -1706,7 +1718,11 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             break;
         case CP_STAGE_APPLY_AT:
             launch_mf_applyAT(h, P, h->P[1], h->xtmp);
-            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, h->nblk, h->part, dev_buf);
+            {
+                int nrows_l = 0;
+                const double *rows_l = staged_partials(h, h->nblk, &nrows_l);
+                hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, nrows_l, rows_l, dev_buf);
+            }
             std::swap(h->X[1], h->xtmp);
             break;
         default:
