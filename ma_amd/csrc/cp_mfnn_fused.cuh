@@ -85,7 +85,6 @@ __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParam
                                                              const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
     constexpr int NWV = NT / 64;
     __shared__ double tiles[NWV * 2 * 16 * CP_TS];
-    __shared__ double red[NWV * CP_NSCAL];
     __shared__ double Wl[CP_KMAX * CP_KMAX];
     // the control words and W are requested together: one global round trip before the first tile instead of three
     // (it is a visible part of the 40 us a launch takes on the coarse pyramid levels)
@@ -262,10 +261,42 @@ __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParam
             sums[DS_UY] += vmask * uy;
         }
     }
+    // partial row of this workgroup: every wave stages its 20 scalars and both Gram accumulators in its OWN tile region
+    // (no barrier needed before), one barrier, fixed-order sum over the waves (same order as block_reduce_store /
+    // gram_block_store, which took six barriers)
     double *out = part + (size_t)blockIdx.x * CP_PSTRIDE;
-    block_reduce_store<CP_NSUM, CP_NMAX, NWV>(sums, maxs, red, out);
-    gram_block_store<NWV>(acc1, tiles, out + CP_NSCAL);
-    gram_block_store<NWV>(acc2, tiles, out + CP_NSCAL + 256);
+    {
+        constexpr int WS = 2 * 16 * CP_TS;   // doubles per wave in tiles[]
+        static_assert(WS >= CP_PSTRIDE, "tile region too small for the staged partial row");
+        double *st = tiles + wave * WS;
+#pragma unroll
+        for (int a = 0; a < CP_NSUM; ++a) {
+            const double v = wave_sum(sums[a]);
+            if (lane == 0) st[a] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < CP_NMAX; ++a) {
+            const double v = wave_max(maxs[a]);
+            if (lane == 0) st[CP_NSUM + a] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = ((lane >> 4) + 4 * r) * 16 + (lane & 15);
+            st[CP_NSCAL + e] = acc1[r];
+            st[CP_NSCAL + 256 + e] = acc2[r];
+        }
+        __syncthreads();
+        for (int e = tid; e < CP_PSTRIDE; e += NT) {
+            const bool is_max = (e >= CP_NSUM && e < CP_NSCAL);
+            double v = tiles[e];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) {
+                const double o = tiles[w * WS + e];
+                v = is_max ? fmax(v, o) : v + o;
+            }
+            out[e] = v;
+        }
+    }
 }
 
 struct EFusedArgs {
