@@ -83,6 +83,7 @@ struct cp_engine {
     bool pw_split = false;   // tuning aid (CP_TUNE_PW_SPLIT=1): pairwise models on the split passes instead of k_pw_fused
     int fused_nt = CP_BLOCK;   // threads per workgroup of k_mf_fused_tv (512: CP_TUNE_FUSED_THREADS, with tile width 2)
     int fused_tw = 1;    // image columns per workgroup tile of k_mf_fused_tv
+    int fused_ka = 1;    // use the K <= 8 / K <= 12 instantiations of k_mf_fused_tv (CP_TUNE_FUSED_KA=0: always 16)
     int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU resident: two LDS tiles per wave)
     bool linearized = false, has_nu = false, has_images = false;
     hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless cp_set_stream)
@@ -334,6 +335,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (const char *ev = getenv("CP_TUNE_FUSED_TW")) h->fused_tw = (atoi(ev) == 4) ? 4 : (atoi(ev) == 2 ? 2 : 1);   // tuning knobs
         if (const char *ev = getenv("CP_TUNE_FUSED_THREADS")) { if (atoi(ev) == 512) { h->fused_nt = 512; h->fused_tw = 2; } }
         h->nblk_fused = std::max(1, std::min(fused_tiles(h->m, h->nl, h->fused_tw, h->fused_nt), CP_FUSED_MAXGRID));
+        if (const char *ev = getenv("CP_TUNE_FUSED_KA")) h->fused_ka = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_PW_SPLIT")) h->pw_split = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_TIME_ALL")) h->time_all = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_FUSED_GRID")) h->nblk_fused = std::max(1, std::min(h->nblk_fused, atoi(ev)));
@@ -833,6 +835,11 @@ static void launch_fused_tw(cp_engine *h, const MfParams &P, const double *xp, d
     auto kern = (h->d.bc == CP_BC_LINEAR)
                     ? (h->K == CP_KMAX ? k_mf_fused_tv<S, true, true, TW, NT> : k_mf_fused_tv<S, true, false, TW, NT>)
                     : (h->K == CP_KMAX ? k_mf_fused_tv<S, false, true, TW, NT> : k_mf_fused_tv<S, false, false, TW, NT>);
+    if (TW == 1 && NT == CP_BLOCK && h->K <= 12 && h->fused_ka) {   // production tile shape: image arrays of 8 or 12 instead of 16
+        const bool lin = (h->d.bc == CP_BC_LINEAR);
+        if (h->K <= 8) kern = lin ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, 8> : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, 8>;
+        else kern = lin ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, 12> : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, 12>;
+    }
     hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(NT), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
                        (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
 }

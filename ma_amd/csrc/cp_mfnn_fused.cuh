@@ -75,9 +75,11 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
 // spill-over line of every wave a miss in the XCD's L2; TW = 1 measured best (see cp_create).
 __host__ __device__ inline int fused_tiles(int m, int nl, int tw, int nt = CP_BLOCK) { return ((m + nt / tw - 1) / (nt / tw)) * ((nl + tw - 1) / tw); }
 
+// KA = extent of the per-pixel image arrays (8, 12 or 16 >= K): phase 1 loads, multiplies by W and stores KA images, so
+// K = 10 does not pay for 16 (the Gram tiles stay 16 x 16, zero padded).
 // NT = threads per workgroup: 256 (2 workgroups per CU) or 512 (one workgroup per CU, e.g. TW = 2: two adjacent columns
 // of 256 rows side by side, so that half of the j+1 neighbour loads are lines the other half of the workgroup streams)
-template <typename S, bool LINEAR, bool FULLK, int TW, int NT = CP_BLOCK>
+template <typename S, bool LINEAR, bool FULLK, int TW, int NT = CP_BLOCK, int KA = CP_KMAX>
 __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParams P, const S *__restrict__ xo,
                                                              S *__restrict__ xn, const S *__restrict__ pin,
                                                              S *__restrict__ pout, const S *__restrict__ g,
@@ -97,6 +99,9 @@ __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParam
     const bool linear = LINEAR;
     stage_W(W, Wl);
     if (stopped) return;
+    if (KA < CP_KMAX) {   // tile rows the image loops never touch: zeros for the 16 x 16 Gram tiles
+        for (int k = KA; k < CP_KMAX; ++k) tileA[k * CP_TS + lane] = 0.0;
+    }
     __syncthreads();
     const double sigma = P.sigma, tau = P.tau, theta = P.theta, inv_sigma = 1.0 / P.sigma;
     const S *y3in = pin + 5 * (size_t)K * fs;
@@ -127,32 +132,32 @@ __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParam
 
         // ---- phase 1: everything that couples the K images of this pixel --------------------------------
         // all 3K loads are issued up front (image index clamped for K < 16; FULLK folds the guards away)
-        double a[CP_KMAX], Lr[CP_KMAX], y1v[CP_KMAX];
+        double a[KA], Lr[KA], y1v[KA];
         {
-            double t3[CP_KMAX];
+            double t3[KA];
 #pragma unroll
-            for (int k = 0; k < CP_KMAX; ++k) {
+            for (int k = 0; k < KA; ++k) {
                 const int kk = (FULLK || k < K) ? k : K - 1;
                 t3[k] = ldo_stream(y3in + (size_t)kk * fs, off);
                 y1v[k] = ldo(pin + (size_t)kk * fs, off);
                 Lr[k] = ldo_stream(Lin + (size_t)kk * fs, off);
             }
 #pragma unroll
-            for (int kp = 0; kp < CP_KMAX; ++kp) a[kp] = 0.0;
+            for (int kp = 0; kp < KA; ++kp) a[kp] = 0.0;
 #pragma unroll
-            for (int k = 0; k < CP_KMAX; ++k) {
+            for (int k = 0; k < KA; ++k) {
                 const double t = (FULLK || k < K) ? t3[k] : 0.0;
 #pragma unroll
-                for (int kp = 0; kp < CP_KMAX; ++kp) a[kp] = fma(t, Wl[k * CP_KMAX + kp], a[kp]);   // y3_n = y3~_n * W_n
+                for (int kp = 0; kp < KA; ++kp) a[kp] = fma(t, Wl[k * CP_KMAX + kp], a[kp]);   // y3_n = y3~_n * W_n
             }
         }
         double s3 = 0.0;
 #pragma unroll
-        for (int kp = 0; kp < CP_KMAX; ++kp) s3 += a[kp];
+        for (int kp = 0; kp < KA; ++kp) s3 += a[kp];
         const double mean3 = s3 * P.invK;
         double sumL = 0.0, sumLb = 0.0, vLmax = 0.0;
 #pragma unroll
-        for (int k = 0; k < CP_KMAX; ++k) {
+        for (int k = 0; k < KA; ++k) {
             const bool act = FULLK || (k < K);
             const double Lo = Lr[k];
             const double vL = y1v[k] + (a[k] - mean3);               // (A'y)_L = y1 + B*y3
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParam
         if (valid) maxs[PM_VL - CP_NSUM] = fmax(maxs[PM_VL - CP_NSUM], vLmax);
         const double smb = sigma * (sumLb * P.invK), mL = sumL * P.invK;
 #pragma unroll
-        for (int k = 0; k < CP_KMAX; ++k) {
+        for (int k = 0; k < KA; ++k) {
             const bool act = FULLK || (k < K);
             const double v = (valid && act) ? rnd<S>(a[k] - smb) : 0.0;   // y3~_{n+1} = y3_n + sigma*B*Lbar
             tileA[k * CP_TS + lane] = v;
@@ -181,13 +186,13 @@ __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParam
         gram_tile_accum(tileA, acc1);
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < CP_KMAX; ++k)
+        for (int k = 0; k < KA; ++k)
             tileA[k * CP_TS + lane] = (valid && (FULLK || k < K)) ? Lr[k] - mL : 0.0;   // B*L_n
         __syncthreads();
         gram_tile_accum(tileA, acc2);
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < CP_KMAX; ++k) tileA[k * CP_TS + lane] = Lr[k];
+        for (int k = 0; k < KA; ++k) tileA[k * CP_TS + lane] = Lr[k];
 
         // ---- phase 2: per image: displacement part of the primal step (own pixel + 2 neighbours), dual step ----
         // neighbours along i and j ("previous" instead of "next" on a linear boundary row; unused otherwise)
