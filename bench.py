@@ -25,7 +25,7 @@ ELEMS_ITER = {"tv": 37, "curvature": 31}
 # dominant kernel: NN-TV runs one fused kernel per iteration (k_mf_fused_tv: the whole iteration's 37 elements);
 # NN-curvature runs separate passes, the dual pass (reads x(3)+x_old(3)+p(4)+grad(2)+b(1), writes p(4)) dominates
 ELEMS_DOM = {"tv": 37, "curvature": 17}
-DOM_KERNEL = {"tv": "k_mf_fused_tv<double,false,true,1>", "curvature": "k_mf_dual<0,1>"}
+DOM_KERNEL = {"tv": "k_mf_fused_tv<double,false,true,1,256,16>", "curvature": "k_mf_dual<0,1>"}
 
 
 def measured_copy_gbs(dev):
