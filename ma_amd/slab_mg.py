@@ -154,15 +154,19 @@ class MultiGpuEngine:
         if c.left is not None:
             self.eng.halo_unpack(buf, sel, 0, rl.data_ptr())
 
-    def _exchange_both_begin(self, buf, sel):
-        """_exchange_both in two halves: pack + start the messages here, wait + unpack in _exchange_both_end, so that
-        whatever is enqueued in between (all-gather, single-workgroup kernel) hides the transfer"""
+    def _exchange_both_pack(self, buf, sel):
+        """_exchange_both in three parts: pack, start the messages (_exchange_both_begin), wait + unpack
+        (_exchange_both_end), so that the kernel enqueued between the last two hides the transfer"""
         sl, rr, sr, rl = self.hbuf[sel]
         c = self.comm
         if c.left is not None:
             self.eng.halo_pack(buf, sel, 0, sl.data_ptr())
         if c.right is not None:
             self.eng.halo_pack(buf, sel, 1, sr.data_ptr())
+
+    def _exchange_both_begin(self, sel):
+        sl, rr, sr, rl = self.hbuf[sel]
+        c = self.comm
         return c.exchange_begin(to_left=sl if c.left is not None else None, to_right=sr if c.right is not None else None,
                                 from_left=rl if c.left is not None else None, from_right=rr if c.right is not None else None)
 
@@ -286,19 +290,23 @@ class MultiGpuEngine:
         one halo message per neighbour that is in flight during the eigensolve"""
         eng, w = self.eng, self.part.world
         if not self.fused:
-            # split passes: dual -> [halo(y2) | gather -> eig] -> primal -> [halo(u) | gather -> fin]: the halo messages
+            # split passes: dual -> gather -> [halo(y2) | eig] -> primal -> gather -> [halo(u) | fin]: the halo messages
             # (both directions, the Laplacian is symmetric) need nothing from the single-workgroup kernels -- y2 is not
-            # touched by the eigensolve, the stored u carries its mean offset lazily -- so they are in flight meanwhile
+            # touched by the eigensolve, the stored u carries its mean offset lazily -- so they are in flight meanwhile.
+            # They are issued AFTER the gather (as in the fused path): the gather is on the critical path and must not
+            # queue behind a megabyte of halo data if RCCL runs both on one stream.
             for n in range(self.it_n + 1, self.it_n + iters + 1):
                 pb, xb = E.BUF_P0 + (n & 1), E.BUF_X0 + (n & 1)
                 eng.mg_stage(E.STAGE_SPLIT_DUAL, n, self.red.data_ptr())
-                tok = self._exchange_both_begin(pb, E.SEL_P_Y2)
+                self._exchange_both_pack(pb, E.SEL_P_Y2)
                 self.comm.all_gather(self.gathered, self.red)
+                tok = self._exchange_both_begin(E.SEL_P_Y2)
                 eng.mg_stage(E.STAGE_SPLIT_EIG, n, self.gathered.data_ptr(), world=w, check_stop=check_stop, tol=tol)
                 self._exchange_both_end(tok, pb, E.SEL_P_Y2)
                 eng.mg_stage(E.STAGE_SPLIT_PRIMAL, n, self.red.data_ptr())
-                tok = self._exchange_both_begin(xb, E.SEL_X_U)
+                self._exchange_both_pack(xb, E.SEL_X_U)
                 self.comm.all_gather(self.gathered, self.red)
+                tok = self._exchange_both_begin(E.SEL_X_U)
                 eng.mg_stage(E.STAGE_SPLIT_FIN, n, self.gathered.data_ptr(), world=w)
                 self._exchange_both_end(tok, xb, E.SEL_X_U)
             self.it_n += iters
