@@ -835,9 +835,10 @@ static void launch_fused_tw(cp_engine *h, const MfParams &P, const double *xp, d
     auto kern = (h->d.bc == CP_BC_LINEAR)
                     ? (h->K == CP_KMAX ? k_mf_fused_tv<S, true, true, TW, NT> : k_mf_fused_tv<S, true, false, TW, NT>)
                     : (h->K == CP_KMAX ? k_mf_fused_tv<S, false, true, TW, NT> : k_mf_fused_tv<S, false, false, TW, NT>);
-    if (TW == 1 && NT == CP_BLOCK && h->K <= 12 && h->fused_ka) {   // production tile shape: image arrays of 8 or 12 instead of 16
+    if (TW == 1 && NT == CP_BLOCK && h->K <= 12 && h->fused_ka) {   // production tile shape: image arrays of 4, 8 or 12 instead of 16
         const bool lin = (h->d.bc == CP_BC_LINEAR);
-        if (h->K <= 8) kern = lin ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, 8> : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, 8>;
+        if (h->K <= 4) kern = lin ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, 4> : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, 4>;
+        else if (h->K <= 8) kern = lin ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, 8> : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, 8>;
         else kern = lin ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, 12> : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, 12>;
     }
     hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(NT), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,

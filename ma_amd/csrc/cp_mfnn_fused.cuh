@@ -75,7 +75,7 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
 // spill-over line of every wave a miss in the XCD's L2; TW = 1 measured best (see cp_create).
 __host__ __device__ inline int fused_tiles(int m, int nl, int tw, int nt = CP_BLOCK) { return ((m + nt / tw - 1) / (nt / tw)) * ((nl + tw - 1) / tw); }
 
-// KA = extent of the per-pixel image arrays (8, 12 or 16 >= K): phase 1 loads, multiplies by W and stores KA images, so
+// KA = extent of the per-pixel image arrays (4, 8, 12 or 16 >= K): phase 1 loads, multiplies by W and stores KA images, so
 // K = 10 does not pay for 16 (the Gram tiles stay 16 x 16, zero padded).
 // NT = threads per workgroup: 256 (2 workgroups per CU) or 512 (one workgroup per CU, e.g. TW = 2: two adjacent columns
 // of 256 rows side by side, so that half of the j+1 neighbour loads are lines the other half of the workgroup streams)
