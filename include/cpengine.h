@@ -72,7 +72,12 @@ enum cp_flag { CP_FLAG_VAR_SSD_SWAP = 1,
                 * and linearisation (T(u0), grad T, b) are stored as float on the device -- half the HBM traffic
                 * per iteration; arithmetic, reductions, eigensolves, the power iteration and histories stay fp64. The host interface is unchanged (double buffers in and out). Tolerance vs the fp64 mode:
                 * 1e-4 relative on the displacement field and the energies (north_star). */
-               CP_FLAG_FP32 = 2 };
+               CP_FLAG_FP32 = 2,
+               /* CP_MODEL_MF_NN_TV only: the single-level driver NNE/mf_nn_tv_registration_no_ref.m composes F as
+                * F1 = SAD(y1, b, 1, sigma) (:206,230) and F2 = sum_j norm21(y2_j, mu, sigma) (:209-216,232-241) --
+                * weights 1 and mu without prod(h_grid), and mu*||.||_{2,1} (NNE/norm21.m) in place of the pointwise
+                * 2x2 nuclear norm of the _ml driver (NNE/mf_nn_tv_registration_no_ref_ml.m:263-264,289-290). */
+               CP_FLAG_MFNN_NORM21 = 4 };
 
 typedef struct cp_problem_desc {
     int32_t model;      /* CP_MODEL_*                                                        */

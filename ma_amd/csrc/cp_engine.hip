@@ -105,6 +105,8 @@ static MfParams mf_params(const cp_engine *h, double theta, double tau, double s
     P.inv_h1 = 1.0 / h->d.h[0]; P.inv_h2 = 1.0 / h->d.h[1];
     P.mu1 = h->d.h[0] * h->d.h[1];              // prod(h_grid), NNE/mf_nn_tv...:257
     P.mu2 = h->d.mu * (h->d.h[0] * h->d.h[1]);  // mu * prod(h_grid), :264
+    P.norm21 = (h->d.flags & CP_FLAG_MFNN_NORM21) ? 1 : 0;
+    if (P.norm21) { P.mu1 = 1.0; P.mu2 = h->d.mu; }   // SAD(y1, b, 1, ..), norm21(y2_j, mu, ..): NNE/mf_nn_tv_registration_no_ref.m:206,213
     P.sigma = sigma; P.tau = tau; P.theta = theta;
     P.ssd_swap = (h->d.flags & CP_FLAG_VAR_SSD_SWAP) ? 1 : 0;
     P.invK = 1.0 / (double)h->K;
@@ -254,6 +256,8 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");   // finite_difference_operator.m:35
         if (d.bc < 0 || d.bc > 2) CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");
         if (d.batch > 1) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported batch > 1 for mf_nn models");
+        if ((d.flags & CP_FLAG_MFNN_NORM21) && d.model != CP_MODEL_MF_NN_TV)
+            CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg CP_FLAG_MFNN_NORM21 belongs to CP_MODEL_MF_NN_TV");
         if (d.n_global > 0 && d.n_global != d.n) {
             // the linear boundary row couples every column with the last one (finite_difference_operator.m:31)
             if (var || d.bc == CP_BC_LINEAR)
@@ -335,6 +339,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (const char *ev = getenv("CP_TUNE_FUSED_TW")) h->fused_tw = (atoi(ev) == 4) ? 4 : (atoi(ev) == 2 ? 2 : 1);   // tuning knobs
         if (const char *ev = getenv("CP_TUNE_FUSED_THREADS")) { if (atoi(ev) == 512) { h->fused_nt = 512; h->fused_tw = 2; } }
         h->nblk_fused = std::max(1, std::min(fused_tiles(h->m, h->nl, h->fused_tw, h->fused_nt), CP_FUSED_MAXGRID));
+        if (d.flags & CP_FLAG_MFNN_NORM21) { h->fused_nt = CP_BLOCK; h->fused_tw = 1; h->nblk_fused = std::max(1, std::min(fused_tiles(h->m, h->nl, 1, CP_BLOCK), CP_FUSED_MAXGRID)); }
         if (const char *ev = getenv("CP_TUNE_FUSED_KA")) h->fused_ka = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_PW_SPLIT")) h->pw_split = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_TIME_ALL")) h->time_all = atoi(ev) != 0;
@@ -753,6 +758,7 @@ static EigArgs eig_args(const cp_engine *h, const MfParams &P, int rp, int rd, i
     A.tau = P.tau;
     A.nblk = h->nblk; A.K = h->K; A.reg = h->reg; A.rp = rp; A.rd = rd; A.check_stop = check; A.update = update;
     A.newbuf = newbuf; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2; A.sigma = P.sigma; A.Ntot = P.Ntot;
+    A.norm21 = P.norm21;
     A.vwarm = nullptr; A.warm = 0;   // cold eigensolve, nothing kept (monitor rows, start-up); see eig_args_warm
     return A;
 }
@@ -841,6 +847,11 @@ static void launch_fused_tw(cp_engine *h, const MfParams &P, const double *xp, d
         else if (h->K <= 8) kern = lin ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, 8> : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, 8>;
         else kern = lin ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, 12> : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, 12>;
     }
+    if constexpr (TW == 1 && NT == CP_BLOCK) {   // (the tile-shape tuning knobs are ignored in this mode, see cp_create)
+        if (P.norm21)   // single-level driver (NNE/mf_nn_tv_registration_no_ref.m): one instantiation per boundary condition
+            kern = (h->d.bc == CP_BC_LINEAR) ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, CP_KMAX, true>
+                                              : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, CP_KMAX, true>;
+    }
     hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(NT), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
                        (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
 }
@@ -871,7 +882,7 @@ static int mf_fused_iterations(cp_engine *h, const MfParams &P, int n0, int coun
         CPCHK(timer_end(h, T_DUAL));
         EFusedArgs A;
         A.K = h->K; A.n = n; A.check_stop = check; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
-        A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot;
+        A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot; A.norm21 = P.norm21;
         A.warm = efused_warm(n);
         if (h->time_all) CPCHK(timer_begin(h, T_EIG));
         const double *rows = fused_partials(h, &A.nblk);
@@ -1675,7 +1686,7 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
         case CP_STAGE_EFUSED: {
             EFusedArgs A;
             A.nblk = world; A.K = h->K; A.n = n; A.check_stop = check_stop; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
-            A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot;
+            A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot; A.norm21 = P.norm21;
             A.warm = efused_warm(n);
             if (h->time_all) CPCHK(timer_begin(h, T_EIG));
             hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->W[(n + 1) & 1],

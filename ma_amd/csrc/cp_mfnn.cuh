@@ -38,6 +38,7 @@ struct MfParams {
     int bc;
     int fs;
     int ssd_swap;             // CP_FLAG_VAR_SSD_SWAP (variance models only)
+    int norm21;               // CP_FLAG_MFNN_NORM21: F2 = mu*||.||_{2,1} per image instead of the pointwise 2x2 nuclear norm
     double inv_h1, inv_h2;
     double mu1, mu2;          // h1*h2, mu*h1*h2
     double sigma, tau, theta;
@@ -190,26 +191,36 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const S *__res
                     const double e2 = fwd_diff(uyb, uybi, uybi, last_i, linear, P.inv_h1);
                     const double e3 = fwd_diff(uyb, uybj, uybj, last_j, linear, P.inv_h2);
                     double s1v, s2v;
-                    sv_2x2(d0, d1, d2, d3, s1v, s2v);
-                    sums[DS_F2] += s1v + s2v;                          // NNE/pointwise_2x2_nn.m:32
+                    if (P.norm21) sums[DS_F2] += sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);   // NNE/norm21.m:52-56
+                    else {
+                        sv_2x2(d0, d1, d2, d3, s1v, s2v);
+                        sums[DS_F2] += s1v + s2v;                      // NNE/pointwise_2x2_nn.m:32
+                    }
                     const S *y2 = pin + (size_t)(K + 4 * k) * fs + e;
                     const double v0 = y2[0], v1 = y2[(size_t)fs], v2 = y2[2 * (size_t)fs], v3 = y2[3 * (size_t)fs];
                     double n0, n1, n2, n3;
                     if (MODE == 0) {
                         const double t0 = v0 + sigma * e0, t1 = v1 + sigma * e1, t2 = v2 + sigma * e2,
                                      t3 = v3 + sigma * e3;
-                        // NNE/pointwise_2x2_nn.m:46-48: M - tau * SVT_{mu/tau}(M / tau)
-                        double r0, r1, r2, r3;
-                        svt_2x2(t0 * inv_sigma, t1 * inv_sigma, t2 * inv_sigma, t3 * inv_sigma, P.mu2 * inv_sigma, r0,
-                                r1, r2, r3);
-                        n0 = rnd<S>(t0 - sigma * r0); n1 = rnd<S>(t1 - sigma * r1);
-                        n2 = rnd<S>(t2 - sigma * r2); n3 = rnd<S>(t3 - sigma * r3);
+                        if (P.norm21) {
+                            const double nn = fmax(sqrt(t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3), P.mu2);   // NNE/norm21.m:70
+                            n0 = rnd<S>((P.mu2 * t0) / nn); n1 = rnd<S>((P.mu2 * t1) / nn);               // :71
+                            n2 = rnd<S>((P.mu2 * t2) / nn); n3 = rnd<S>((P.mu2 * t3) / nn);
+                        } else {
+                            // NNE/pointwise_2x2_nn.m:46-48: M - tau * SVT_{mu/tau}(M / tau)
+                            double r0, r1, r2, r3;
+                            svt_2x2(t0 * inv_sigma, t1 * inv_sigma, t2 * inv_sigma, t3 * inv_sigma, P.mu2 * inv_sigma, r0,
+                                    r1, r2, r3);
+                            n0 = rnd<S>(t0 - sigma * r0); n1 = rnd<S>(t1 - sigma * r1);
+                            n2 = rnd<S>(t2 - sigma * r2); n3 = rnd<S>(t3 - sigma * r3);
+                        }
                         S *o2 = pout + (size_t)(K + 4 * k) * fs + e;
                         o2[0] = (S)n0; o2[(size_t)fs] = (S)n1; o2[2 * (size_t)fs] = (S)n2; o2[3 * (size_t)fs] = (S)n3;
                     } else {
                         n0 = v0; n1 = v1; n2 = v2; n3 = v3;
                     }
-                    sv_2x2(n0, n1, n2, n3, s1v, s2v);
+                    if (P.norm21) s1v = sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);   // NNE/norm21.m:65,81
+                    else sv_2x2(n0, n1, n2, n3, s1v, s2v);
                     maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], s1v);   // NNE/pointwise_2x2_nn.m:56
                 } else {
                     // 5-point Laplacian, NNE/discrete_laplacian.m:23-46: a missing neighbour is the centre value

@@ -79,7 +79,8 @@ __host__ __device__ inline int fused_tiles(int m, int nl, int tw, int nt = CP_BL
 // K = 10 does not pay for 16 (the Gram tiles stay 16 x 16, zero padded).
 // NT = threads per workgroup: 256 (2 workgroups per CU) or 512 (one workgroup per CU, e.g. TW = 2: two adjacent columns
 // of 256 rows side by side, so that half of the j+1 neighbour loads are lines the other half of the workgroup streams)
-template <typename S, bool LINEAR, bool FULLK, int TW, int NT = CP_BLOCK, int KA = CP_KMAX>
+// N21: F2 = mu*||.||_{2,1} (NNE/norm21.m, the single-level driver) instead of the pointwise 2x2 nuclear norm
+template <typename S, bool LINEAR, bool FULLK, int TW, int NT = CP_BLOCK, int KA = CP_KMAX, bool N21 = false>
 __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParams P, const S *__restrict__ xo,
                                                              S *__restrict__ xn, const S *__restrict__ pin,
                                                              S *__restrict__ pout, const S *__restrict__ g,
@@ -250,10 +251,18 @@ __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParam
             const double e1 = fwd_diff(uxb, uxbj, uxbj, last_j, linear, P.inv_h2);
             const double e2 = fwd_diff(uyb, uybi, uybi, last_i, linear, P.inv_h1);
             const double e3 = fwd_diff(uyb, uybj, uybj, last_j, linear, P.inv_h2);
-            sums[DS_F2] += vmask * nuc_2x2(d0, d1, d2, d3);                    // NNE/pointwise_2x2_nn.m:32
             const double t0 = v0 + sigma * e0, t1 = v1 + sigma * e1, t2 = v2 + sigma * e2, t3 = v3 + sigma * e3;
             double n0, n1, n2, n3, s1v;
-            proj_spectral_2x2(t0, t1, t2, t3, P.mu2, n0, n1, n2, n3, s1v);     // :46-48 (Moreau), :56
+            if (N21) {
+                sums[DS_F2] += vmask * sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);           // NNE/norm21.m:52-56
+                const double nn = fmax(sqrt(t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3), P.mu2);   // :70
+                n0 = (P.mu2 * t0) / nn; n1 = (P.mu2 * t1) / nn; n2 = (P.mu2 * t2) / nn; n3 = (P.mu2 * t3) / nn;   // :71
+                n0 = rnd<S>(n0); n1 = rnd<S>(n1); n2 = rnd<S>(n2); n3 = rnd<S>(n3);
+                s1v = sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);                            // :65,81
+            } else {
+                sums[DS_F2] += vmask * nuc_2x2(d0, d1, d2, d3);                // NNE/pointwise_2x2_nn.m:32
+                proj_spectral_2x2(t0, t1, t2, t3, P.mu2, n0, n1, n2, n3, s1v); // :46-48 (Moreau), :56
+            }
             if (sizeof(S) == 4) { n0 = rnd<S>(n0); n1 = rnd<S>(n1); n2 = rnd<S>(n2); n3 = rnd<S>(n3); }
             if (valid) {
                 S *o1 = pout + (size_t)k * fs, *o2 = pout + ((size_t)K + 4 * (size_t)k) * fs;
@@ -309,6 +318,7 @@ struct EFusedArgs {
     int nblk, K;
     int n;               // iteration: completes primal row n and dual row n, starts dual row n+1
     int check_stop;
+    int norm21;          // F2 = mu*||.||_{2,1}: its conjugate's violation is max||v|| - mu (NNE/norm21.m:81-85), not relative
     double tol, mu1, mu2, sigma, tau, Ntot;
 };
 
@@ -383,7 +393,8 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
         hd1[2] = 0.0;
         hd1[3] = nu * res[0];
         const double con1 = (sc[DM_Y1] > A.mu1) ? sc[DM_Y1] - A.mu1 : 0.0;
-        const double con2 = fmax((sc[DM_S1] - A.mu2) / A.mu2, 0.0);
+        const double con2 = A.norm21 ? ((sc[DM_S1] > A.mu2) ? sc[DM_S1] - A.mu2 : 0.0)   // NNE/norm21.m:81-85
+                                     : fmax((sc[DM_S1] - A.mu2) / A.mu2, 0.0);           // NNE/pointwise_2x2_nn.m:52-57
         hd1[5] = fmax(con1, con2);
         // mean of the next un-projected u
         ctrl->cn[0] = sc[DS_UX] / A.Ntot + A.tau * (sc[DS_SGX] / A.Ntot);

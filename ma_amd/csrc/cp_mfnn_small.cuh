@@ -22,6 +22,7 @@ struct EigArgs {
     int newbuf;
     int monitor;         // eig: the dual row describes y_in itself (row 0), not the projected y
     int compute_cn;      // eig: store the mean of the next un-projected u into ctrl->cn (start of the fused passes)
+    int norm21;          // F2 = mu*||.||_{2,1} (CP_FLAG_MFNN_NORM21): absolute violation measure, NNE/norm21.m:81-85
     double tau;
     double tol, mu1, mu2, sigma, Ntot;
     double *vwarm;       // 256 doubles: eigenvector basis of this kernel's matrix from the previous iteration (or null)
@@ -420,7 +421,9 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_eig(EigArgs A, const doub
             // nuclear_norm_constraint.m:89: nu * max(svd(y3)); the singular values of the projected y3 are S_prox
             hd[3] = nu * (A.monitor ? smax : spmax);
             const double con1 = (sc[DM_Y1] > A.mu1) ? sc[DM_Y1] - A.mu1 : 0.0;     // NNE/SAD.m:77-81
-            const double con2 = (A.reg == 0) ? fmax((sc[DM_S1] - A.mu2) / A.mu2, 0.0) : 0.0;
+            const double con2 = (A.reg != 0) ? 0.0
+                                : (A.norm21 ? ((sc[DM_S1] > A.mu2) ? sc[DM_S1] - A.mu2 : 0.0)
+                                            : fmax((sc[DM_S1] - A.mu2) / A.mu2, 0.0));
             hd[5] = fmax(fmax(con1, con2), 0.0);
         }
         if (A.compute_cn) {

@@ -186,8 +186,10 @@ def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_
     try:
         for (ml, nl) in sizes:
             h_grid = ((omega[1] - omega[0]) / ml, (omega[3] - omega[2]) / nl)          # (:88)
+            # the single-level driver's F: SAD weight 1, norm21 with weight mu (NNE/mf_nn_tv_registration_no_ref.m:206-216)
+            flags = (E.FLAG_FP32 if fp32 else 0) | (E.FLAG_MFNN_NORM21 if single_level else 0)
             engines.append(E.Engine(model, ml, nl, k=k, bc=optPara["bc"], h=h_grid, omega=omega, mu=optPara["mu"],
-                                    device=device, flags=E.FLAG_FP32 if fp32 else 0))
+                                    device=device, flags=flags))
         engines[-1].set_images(np.concatenate([_vecF(im) for im in img]))
         for lev in range(levels - 1, 0, -1):
             engines[lev].downsample_to(engines[lev - 1])
@@ -201,7 +203,7 @@ def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_
             if lev > 0:
                 eng.prolong_from(engines[lev - 1], 1.0)                                # (:111-119), p = 0 (:122)
                 engines[lev - 1].close()
-            SV_history[lev] = np.zeros((k, max_outer))
+            SV_history[lev] = np.zeros((k, outerIter))                                 # (:153): this level's outerIter
             for o in range(outerIter):
                 eng.linearize()                                                        # (:164-169)
                 if o == 0 and lev == 0:
@@ -270,7 +272,9 @@ def _var_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_al
     try:
         for (ml, nl) in sizes:
             h_grid = ((omega[1] - omega[0]) / ml, (omega[3] - omega[2]) / nl)          # (:85)
-            engines.append(E.Engine(model, ml, nl, k=k, bc=optPara["bc"], h=h_grid, omega=omega, mu=optPara["mu"],
+            # the variance drivers call evaluate_displacement without omega (:147-148): the engine's default region
+            # [0, m*h1, 0, n*h2] is that call's default (IRE/evaluate_displacement.m:34-36)
+            engines.append(E.Engine(model, ml, nl, k=k, bc=optPara["bc"], h=h_grid, omega=None, mu=optPara["mu"],
                                     device=device, flags=flags))
         engines[-1].set_images(np.concatenate([_vecF(im) for im in img]))
         for lev in range(levels - 1, 0, -1):

@@ -15,6 +15,7 @@ MODEL_TV_L1_DENOISE, MODEL_TV_L1_REG, MODEL_TV_L2_REG, MODEL_MF_NN_TV, MODEL_MF_
 MODEL_VAR_TV, MODEL_VAR_CURV = 6, 7
 FLAG_VAR_SSD_SWAP = 1
 FLAG_FP32 = 2
+FLAG_MFNN_NORM21 = 4
 BC = {"neumann": 0, "linear": 1, "dirichlet": 2}
 STOP_MAXITER, STOP_TOLERANCE = 0, 1
 
@@ -367,3 +368,4 @@ class Engine:
         n = C.c_int64()
         _chk(lib.cp_kernel_time_ms(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+

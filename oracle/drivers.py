@@ -60,8 +60,12 @@ def tv_l1_denoising(img_noisy, lam=1.5, tau=0.02, maxIter=1000, tol=1e-5, h=(1.0
 
 # --------------------------------------------------------------------------
 # NNE/mf_nn_tv_registration_no_ref_ml.m / NNE/mf_nn_curvature_registration_no_ref_ml.m
-def mf_nn_F(y, b, k, h_grid, mu, nu, sigma, conjugate_flag, nargout, reg):
-    """Local function F of the drivers (mf_nn_tv...:235-305; mf_nn_curvature...:230-291)."""
+def mf_nn_F(y, b, k, h_grid, mu, nu, sigma, conjugate_flag, nargout, reg, single_level=False):
+    """Local function F of the drivers (mf_nn_tv...:235-305; mf_nn_curvature...:230-291).
+
+    single_level: the F of NNE/mf_nn_tv_registration_no_ref.m:184-253 -- SAD(y1, b, 1, sigma) (:206,230) and
+    norm21(y2_j, mu, sigma) per image (:211-216,236-241): weights 1 and mu (no prod(h_grid)), mu*||.||_{2,1} where the
+    _ml driver has the pointwise 2x2 nuclear norm (mf_nn_tv..._ml.m:263-264,289-290 keep norm21 only as a comment)."""
     ncomp = 6 if reg == "tv" else 4
     mn = y.size // (ncomp * k)
     n2 = ncomp - 2
@@ -69,6 +73,11 @@ def mf_nn_F(y, b, k, h_grid, mu, nu, sigma, conjugate_flag, nargout, reg):
     y2 = y[k * mn: (n2 + 1) * k * mn]
     y3 = y[(n2 + 1) * k * mn:]
     hh = float(np.prod(h_grid))
+    F2 = px.pointwise_2x2_nn
+    if single_level:
+        assert reg == "tv"
+        hh = 1.0
+        F2 = px.norm21
     if nargout == 3:
         res3 = np.zeros(ncomp * k * mn)
         res3[: k * mn] = px.SAD(y1, b, hh, sigma, conjugate_flag, 3)[2]
@@ -76,7 +85,7 @@ def mf_nn_F(y, b, k, h_grid, mu, nu, sigma, conjugate_flag, nargout, reg):
             Y2 = y2.reshape((4 * mn, k), order="F")
             for j in range(k):
                 res3[k * mn + j * 4 * mn: k * mn + (j + 1) * 4 * mn] = \
-                    px.pointwise_2x2_nn(Y2[:, j], mu * hh, sigma, conjugate_flag, 3)[2]
+                    F2(Y2[:, j], mu * hh, sigma, conjugate_flag, 3)[2]
         else:
             g0 = np.zeros(2 * k * mn)
             res3[k * mn: 3 * k * mn] = px.SSD(y2, g0, mu * hh, sigma, conjugate_flag, 3)[2]
@@ -88,7 +97,7 @@ def mf_nn_F(y, b, k, h_grid, mu, nu, sigma, conjugate_flag, nargout, reg):
         r1_F2 = 0.0
         r2_F2 = 0.0
         for j in range(k):
-            a, c, _ = px.pointwise_2x2_nn(Y2[:, j], mu * hh, sigma, conjugate_flag, 2)
+            a, c, _ = F2(Y2[:, j], mu * hh, sigma, conjugate_flag, 2)
             r1_F2 = r1_F2 + a
             r2_F2 = max(r2_F2, c)
     else:
@@ -163,7 +172,7 @@ def mf_nn_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_star
         s = (m, n, k)
         Gh = lambda xx, c, nargout: mf_nn_G(xx, s, c, nargout)
         u0 = x[: 2 * kmn].reshape((m * n, 2, k), order="F")
-        SV_history[lev] = np.zeros((k, max_outer))
+        SV_history[lev] = np.zeros((k, outerIter))                                # zeros(k, max(outerIter)), outerIter = this level's (:153)
         for o in range(outerIter):
             b = np.zeros(kmn)
             T_u = np.zeros((m, n, k))
@@ -188,7 +197,7 @@ def mf_nn_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_star
             tau = np.sqrt(0.99 / norm_A_est ** 2)                                # (:195-196)
             sigma = np.sqrt(0.99 / norm_A_est ** 2)
             nu_ = nu
-            Fh = lambda y, c, nargout: mf_nn_F(y, b, k, h_grid, mu, nu_, sigma, c, nargout, reg)
+            Fh = lambda y, c, nargout: mf_nn_F(y, b, k, h_grid, mu, nu_, sigma, c, nargout, reg, single_level)
             x, p, ph, dh = chambolle_pock(Fh, Gh, A, x, p, theta, tau, sigma, maxIter, tol)
             u0 = x[: 2 * kmn].reshape((m * n, 2, k), order="F")
             L0 = x[2 * kmn:]
@@ -321,7 +330,9 @@ def var_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start,
         Gh = lambda xx, c, nargout: px.mean_zero_indicator(xx, s, c, nargout)    # (:126)
         u0 = x.reshape((m * n, 2, k), order="F")
         for o in range(outerIter):
-            A, b, _, _ = var_problem([ML[i][lev] for i in range(k)], u0, h_grid, omega, reg, bc)
+            # evaluate_displacement is called WITHOUT omega here (var_tv...:147-148, var_curvature...:146-147): its
+            # default [0, m*h1, 0, n*h2] (IRE/evaluate_displacement.m:34-36) is used, m*(M/m) in floating point
+            A, b, _, _ = var_problem([ML[i][lev] for i in range(k)], u0, h_grid, None, reg, bc)
             e = ops.matrix_norm(A, normest_x0(A.shape[1]) if normest_x0 is not None else None)
             norm_A_est = e[-1]
             tau = np.sqrt(0.99 / norm_A_est ** 2)                                # (:168-169)

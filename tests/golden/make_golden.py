@@ -247,13 +247,47 @@ def var_e2e():
     np.savez_compressed(os.path.join(HERE, "var_e2e.npz"), **out)
 
 
+def single_level_e2e():
+    """single-level drivers NNE/mf_nn_tv_registration_no_ref.m (F1 = SAD weight 1, F2 = norm21 weight mu, :206-216) and
+    NNE/var_tv_registration_no_ref.m (swapped SSD prox arguments, :173) on 56 x 48, K = 3 (the _ml drivers would still
+    use one level here, so the difference to them is the functional alone)"""
+    out = {}
+    m, n, k = 56, 48, 3
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    out["imgs"] = imgs
+    opt = dict(theta=1.0, maxIter=50, tol=1e-3, outerIter=3, mu=0.15, nu_factor=0.9, bc="linear")
+    keep = {}
+    u, L, SV = od.mf_nn_registration_no_ref_ml([imgs[i] for i in range(k)], opt, "tv", keep=keep, single_level=True)
+    out["mfnn_SV"] = SV[0]
+    for o in range(3):
+        kk = keep[(0, o)]
+        out[f"mfnn_u_{o}"] = u[0][o]
+        out[f"mfnn_L_{o}"] = L[0][o]
+        out[f"mfnn_sched_{o}"] = np.array([kk["nu"], kk["tau"], kk["norm_est"], kk["n_power"], kk["primal_history"].shape[0]])
+        out[f"mfnn_ph_{o}"] = kk["primal_history"]
+        out[f"mfnn_dh_{o}"] = kk["dual_history"]
+    # the same inputs through the _ml functional (pointwise 2x2 nuclear norm): must differ, or the fixture pins nothing
+    u_ml, _, _ = od.mf_nn_registration_no_ref_ml([imgs[i] for i in range(k)], dict(opt, outerIter=[3, 3], nu_factor=[0.9, 0.9]), "tv")
+    out["mfnn_ml_u_2"] = u_ml[0][2]
+    optv = dict(theta=1.0, maxIter=50, tol=1e-3, outerIter=3, mu=0.1, bc="neumann")
+    keep = {}
+    uv = od.var_registration_no_ref_ml([imgs[i] for i in range(k)], optv, "tv", keep=keep, single_level=True)
+    for o in range(3):
+        kk = keep[(0, o)]
+        out[f"var_u_{o}"] = uv[0][o]
+        out[f"var_sched_{o}"] = np.array([kk["tau"], kk["norm_est"], kk["n_power"], kk["primal_history"].shape[0]])
+        out[f"var_ph_{o}"] = kk["primal_history"]
+        out[f"var_dh_{o}"] = kk["dual_history"]
+    np.savez_compressed(os.path.join(HERE, "single_level_e2e.npz"), **out)
+
+
 if __name__ == "__main__":
+    only = set(sys.argv[1:])        # e.g. `make_golden.py mfnn single` regenerates two fixtures only
     png = data_png()
-    operators_fixture()
-    warp_fixture(png)
-    pyramid_fixture()
-    pairwise_e2e(png)
-    mfnn_e2e()
-    var_e2e()
+    steps = dict(operators=operators_fixture, warp=lambda: warp_fixture(png), pyramid=pyramid_fixture,
+                 pairwise=lambda: pairwise_e2e(png), mfnn=mfnn_e2e, var=var_e2e, single=single_level_e2e)
+    for name, fn in steps.items():
+        if not only or name in only:
+            fn()
     for f in sorted(glob.glob(os.path.join(HERE, "*.npz"))):
         print(os.path.basename(f), os.path.getsize(f) // 1024, "KiB")

@@ -164,3 +164,39 @@ def test_var_driver_fixture(golden_dir, reg, bc, mu):
             np.testing.assert_allclose(kk["primal_history"], f[f"{reg}_ph_{lev}_{o}"], rtol=1e-8, atol=1e-9)
             np.testing.assert_allclose(kk["dual_history"], f[f"{reg}_dh_{lev}_{o}"], rtol=1e-8, atol=1e-9)
             assert _rel(u[lev][o], f[key]) < 1e-9, (lev, o)
+
+
+def test_single_level_drivers_fixture(golden_dir):
+    """NNE/mf_nn_tv_registration_no_ref.m (F1 = SAD with weight 1, F2 = mu*||.||_{2,1} per image, :206-216,230-241 --
+    CP_FLAG_MFNN_NORM21) and NNE/var_tv_registration_no_ref.m (swapped SSD prox arguments, :173) against the stored runs:
+    3 outer iterations, linear boundary rows, nu schedule, power iteration, histories, stop rule"""
+    from ma_amd import drivers as D
+    f = _load(golden_dir, "single_level_e2e.npz")
+    imgs = f["imgs"]
+    k = imgs.shape[0]
+    opt = dict(theta=1.0, maxIter=50, tol=1e-3, outerIter=3, mu=0.15, nu_factor=0.9, bc="linear")
+    keep = {}
+    u, L, SV = D.mf_nn_tv_registration_no_ref([imgs[i] for i in range(k)], opt, keep=keep)
+    assert SV.shape == f["mfnn_SV"].shape == (k, 3)
+    np.testing.assert_allclose(SV, f["mfnn_SV"], rtol=1e-9, atol=1e-10)
+    for o in range(3):
+        nu, tau, norm_est, n_power, rows = f[f"mfnn_sched_{o}"]
+        kk = keep[(0, o)]
+        assert abs(kk["nu"] - nu) <= 1e-11 * abs(nu) and abs(kk["norm_est"] - norm_est) <= 1e-11 * norm_est
+        assert kk["n_power"] == int(n_power) and kk["primal_history"].shape[0] == int(rows)
+        np.testing.assert_allclose(kk["primal_history"][:, :5], f[f"mfnn_ph_{o}"][:, :5], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(kk["dual_history"], f[f"mfnn_dh_{o}"], rtol=1e-8, atol=1e-8)
+        assert _rel(u[o], f[f"mfnn_u_{o}"]) < 1e-9 and _rel(L[o], f[f"mfnn_L_{o}"]) < 1e-9, o
+    # the functional matters: the _ml arithmetic (pointwise 2x2 nuclear norm) ends somewhere else
+    assert _rel(f["mfnn_ml_u_2"], f["mfnn_u_2"]) > 1e-3
+    optv = dict(theta=1.0, maxIter=50, tol=1e-3, outerIter=3, mu=0.1, bc="neumann")
+    keep = {}
+    uv = D.var_tv_registration_no_ref([imgs[i] for i in range(k)], optv, keep=keep)
+    for o in range(3):
+        tau, norm_est, n_power, rows = f[f"var_sched_{o}"]
+        kk = keep[(0, o)]
+        assert abs(kk["norm_est"] - norm_est) <= 1e-11 * norm_est and kk["n_power"] == int(n_power)
+        assert kk["primal_history"].shape[0] == int(rows)
+        np.testing.assert_allclose(kk["primal_history"], f[f"var_ph_{o}"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(kk["dual_history"], f[f"var_dh_{o}"], rtol=1e-8, atol=1e-9)
+        assert _rel(uv[o], f[f"var_u_{o}"]) < 1e-9, o

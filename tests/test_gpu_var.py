@@ -126,9 +126,18 @@ def test_single_level_drivers():
     # the swap matters: the _ml arithmetic gives a different iterate
     u_ml = od.var_registration_no_ref_ml(imgs, dict(opt, outerIter=[2, 2]), "tv", single_level=False)
     assert len(u_ml) == 2
+    # NNE/mf_nn_tv_registration_no_ref.m: F1 = SAD(y1, b, 1, sigma), F2 = norm21(y2_j, mu, sigma) (:206-216)
     opt2 = dict(theta=1.0, maxIter=30, tol=1e-3, outerIter=2, mu=0.2, nu_factor=0.9, bc="neumann")
-    ur2, Lr2, SVr2 = od.mf_nn_registration_no_ref_ml(imgs, opt2, "tv", single_level=True)
-    ug2, Lg2, SVg2 = D.mf_nn_tv_registration_no_ref(imgs, opt2)
+    keep_r, keep_g = {}, {}
+    ur2, Lr2, SVr2 = od.mf_nn_registration_no_ref_ml(imgs, opt2, "tv", single_level=True, keep=keep_r)
+    ug2, Lg2, SVg2 = D.mf_nn_tv_registration_no_ref(imgs, opt2, normest_x0=od.normest_start, keep=keep_g)
     for o in range(2):
         assert _rel(ug2[o], ur2[0][o]) < 1e-9 and _rel(Lg2[o], Lr2[0][o]) < 1e-9
+        a, b = keep_g[(0, o)], keep_r[(0, o)]
+        assert a["primal_history"].shape == b["primal_history"].shape
+        np.testing.assert_allclose(a["primal_history"][:, :5], b["primal_history"][:, :5], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(a["dual_history"], b["dual_history"], rtol=1e-8, atol=1e-8)
     np.testing.assert_allclose(SVg2, SVr2[0], rtol=1e-9, atol=1e-10)
+    # the _ml functional (pointwise 2x2 nuclear norm) on the same single level gives a different iterate
+    u_nn, _, _ = od.mf_nn_registration_no_ref_ml(imgs, dict(opt2, outerIter=[2, 2], nu_factor=[0.9, 0.9]), "tv")
+    assert len(u_nn) == 2

@@ -66,3 +66,32 @@ def test_var_driver_fixture(golden_dir):
     od.var_registration_no_ref_ml([imgs[i] for i in range(k)], opt, "tv", keep=keep)
     assert np.allclose(keep[(0, 0)]["primal_history"], f["tv_ph_0_0"], rtol=1e-12, atol=1e-12)
     assert abs(keep[(0, 0)]["norm_est"] - f["tv_sched_0_0"][1]) <= 1e-13 * f["tv_sched_0_0"][1]
+
+
+def test_single_level_fixture_and_its_functional(golden_dir):
+    """single-level mf_nn driver: the first outer iteration reproduces the stored run, and its F is the one of
+    NNE/mf_nn_tv_registration_no_ref.m:184-253 -- SAD with weight 1 and mu*||.||_{2,1} per image, checked here directly
+    on the six evaluations the solver uses (not through the driver)"""
+    f = _load(golden_dir, "single_level_e2e.npz")
+    imgs = f["imgs"]
+    k = imgs.shape[0]
+    opt = dict(theta=1.0, maxIter=50, tol=1e-3, outerIter=1, mu=0.15, nu_factor=0.9, bc="linear")
+    keep = {}
+    od.mf_nn_registration_no_ref_ml([imgs[i] for i in range(k)], opt, "tv", keep=keep, single_level=True)
+    assert np.allclose(keep[(0, 0)]["primal_history"], f["mfnn_ph_0"], rtol=1e-12, atol=1e-12)
+    rng = np.random.default_rng(3)
+    mn, mu, nu, sigma = 30, 0.15, 2.0, 0.4
+    y = rng.standard_normal(6 * k * mn)
+    b = rng.standard_normal(k * mn)
+    for conj in (False, True):
+        vals, con, _ = od.mf_nn_F(y, b, k, (2.0, 3.0), mu, nu, sigma, conj, 2, "tv", single_level=True)
+        v1, c1, _ = px.SAD(y[:k * mn], b, 1.0, sigma, conj, 2)                      # weight 1, not prod(h_grid) = 6
+        Y2 = y[k * mn:5 * k * mn].reshape((4 * mn, k), order="F")
+        n21 = [px.norm21(Y2[:, j], mu, sigma, conj, 2) for j in range(k)]
+        v3, c3, _ = px.nuclear_norm_constraint(y[5 * k * mn:], k, sigma, nu, conj, 2)
+        assert np.allclose(vals, [v1, sum(r[0] for r in n21), v3], rtol=1e-15)
+        assert con == max(c1, max(r[1] for r in n21), c3)
+        prox = od.mf_nn_F(y, b, k, (2.0, 3.0), mu, nu, sigma, conj, 3, "tv", single_level=True)[2]
+        assert np.array_equal(prox[:k * mn], px.SAD(y[:k * mn], b, 1.0, sigma, conj, 3)[2])
+        for j in range(k):
+            assert np.array_equal(prox[k * mn + j * 4 * mn: k * mn + (j + 1) * 4 * mn], px.norm21(Y2[:, j], mu, sigma, conj, 3)[2])
