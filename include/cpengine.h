@@ -243,6 +243,21 @@ int cp_mg_gram(cp_handle h, int which, const double *V, double *gram);
 /* power iteration start: fills X1 with the deterministic start vector (global indices), zeroes XTMP    */
 int cp_mg_power_start(cp_handle h, double *local_sumsq);
 
+/* --- allocation-free entry point -------------------------------------------------------------------
+ * No counterpart in the reference. For callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc. A variant of cp_singular_values(h, 0, sv): singular values
+ * (descending, k of them) of reshape(B*field, m*n, k), B = NNE/mean_free_operator.m:20 -- the quantity behind nu_0 and
+ * SV_history (NNE/mf_nn_tv_registration_no_ref_ml.m:173-175,214-215) -- for a caller-owned DEVICE field of k images,
+ * m x n each, column-major, stacked (no halo columns), written to the caller-owned DEVICE buffer dev_sv (k doubles).
+ * Same kernels and arithmetic as cp_singular_values; the per-workgroup partial sums and the 16 x 16 work matrices
+ * live in a static device array of the library (3.3 MB per GPU, held until the process ends) instead of a handle.
+ * Calls no hipMalloc / hipFree and no allocating routine; enqueues on hip_stream (NULL: the default stream) and
+ * returns WITHOUT synchronising -- dev_sv is valid once the stream has reached that point.
+ * Limits: 1 <= k <= 16, m*n <= 2^30; larger inputs are rejected with CP_ERR_UNSUPPORTED.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams or threads) race. */
+int cp_singular_values_static(int32_t device, const double *dev_field, int32_t m, int32_t n, int32_t k,
+                              double *dev_sv, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1825,3 +1825,69 @@ extern "C" int cp_mg_power_start(cp_handle h, double *local_sumsq) {
     *local_sumsq = s;
     return CP_OK;
 }
+
+// ================================================================================================
+// Allocation-free variant of cp_singular_values (include/cpengine.h: cp_singular_values_static). Same kernels, same
+// two passes (Gram of B*field -> Jacobi, second Gram in the rotated basis -> Jacobi), but the per-workgroup partial
+// rows, the rotation and the eigenvalues live in a file-scope device array instead of the handle's hipMalloc'ed
+// buffers, the input is a caller-owned device field and the sorted result goes to a caller-owned device buffer.
+#define CP_NA_MAXBLK 768                                     // = the grid cap of grid_for() for the multi-image models
+#define CP_NA_PART ((size_t)CP_NA_MAXBLK * CP_PSTRIDE)        // partial rows
+#define CP_NA_SCRATCH (CP_NA_PART + 16 + 256 + 256 + 256)     // + eigenvalues, rotation out, identity, rotation in
+static __device__ __align__(256) double scratch[CP_NA_SCRATCH];   // 3.3 MB on every GPU the library runs on
+#define CP_NA_MAXDEV 64
+static double *g_na_ptr[CP_NA_MAXDEV];                        // device address of `scratch` per device (0: not looked up yet)
+
+__global__ void k_na_identity(double *ident) {
+    const int t = threadIdx.x;
+    ident[t] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
+}
+// sv[rank] = sqrt(max(lambda, 0)), descending (rank counting; ties keep their order) -- what the host does in cp_singular_values
+__global__ void k_na_sort(const double *__restrict__ lam, int K, double *__restrict__ sv) {
+    __shared__ double s[16];
+    const int i = threadIdx.x;
+    if (i < 16) s[i] = (i < K) ? sqrt(fmax(lam[i], 0.0)) : -1.0;
+    __syncthreads();
+    if (i < K) {
+        int rank = 0;
+        for (int j = 0; j < K; ++j) rank += (s[j] > s[i] || (s[j] == s[i] && j < i)) ? 1 : 0;
+        sv[rank] = s[i];
+    }
+}
+
+extern "C" int cp_singular_values_static(int32_t device, const double *dev_field, int32_t m, int32_t n, int32_t k,
+                                         double *dev_sv, void *hip_stream) {
+    if (!dev_field || !dev_sv) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_singular_values_static needs a device field and a device output");
+    if (device < 0 || device >= CP_NA_MAXDEV) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg device %d", device);
+    if (m < 1 || n < 1) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg image size %d x %d", m, n);
+    if (k < 1 || k > CP_KMAX)
+        CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_singular_values_static: k = %d exceeds the static scratch (1..%d images)", k, CP_KMAX);
+    if ((long long)m * n > (1LL << 30))
+        CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_singular_values_static: %d x %d pixels exceed the limit of 2^30 per image", m, n);
+    HIPCHK(hipSetDevice(device));
+    if (!g_na_ptr[device]) {   // once per device, with that device current: every GPU holds its own copy of the array
+        double *ptr = nullptr;
+        HIPCHK(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) CP_FAIL(CP_ERR_DEVICE, "cpengine:device hipGetSymbolAddress(scratch) returned a null address");
+        g_na_ptr[device] = ptr;
+    }
+    double *base = g_na_ptr[device];
+    double *part = base, *svout = base + CP_NA_PART, *vout = svout + 16, *ident = svout + 16 + 256, *vin = ident + 256;
+    hipStream_t st = (hipStream_t)hip_stream;
+    MfParams P;
+    memset(&P, 0, sizeof P);
+    P.m = 0;                       // the field has no halo column: element q of image i at i*npix + q
+    P.nl = n; P.K = k; P.npix = m * n; P.n_global = n; P.fs = m * n; P.invK = 1.0 / (double)k;
+    const int nblk = std::max(1, std::min((P.npix + CP_BLOCK - 1) / CP_BLOCK, CP_NA_MAXBLK));
+    // every buffer below is written before it is read within this call; rows of `part` beyond nblk keep an earlier
+    // call's contents and are not read
+    hipLaunchKernelGGL(k_na_identity, dim3(1), dim3(256), 0, st, ident);
+    hipLaunchKernelGGL((k_mf_gram_field<double>), dim3(nblk), dim3(CP_BLOCK), 0, st, P, dev_field, ident, part);
+    hipLaunchKernelGGL(k_mf_sv_eig, dim3(1), dim3(CP_BLOCK), 0, st, nblk, part, ident, svout);
+    HIPCHK(hipMemcpyAsync(vin, vout, sizeof(double) * 256, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL((k_mf_gram_field<double>), dim3(nblk), dim3(CP_BLOCK), 0, st, P, dev_field, vin, part);
+    hipLaunchKernelGGL(k_mf_sv_eig, dim3(1), dim3(CP_BLOCK), 0, st, nblk, part, vin, svout);
+    hipLaunchKernelGGL(k_na_sort, dim3(1), dim3(64), 0, st, svout, k, dev_sv);
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}

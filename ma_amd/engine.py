@@ -87,6 +87,7 @@ def _load():
         "cp_mg_stop_state": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
         "cp_mg_gram": [vp, C.c_int, dp, dp],
         "cp_mg_power_start": [vp, dp],
+        "cp_singular_values_static": [C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -122,7 +123,7 @@ EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_im
             "cp_downsample", "cp_iterate", "cp_iterate_begin", "cp_iterate_steps", "cp_iterate_end", "cp_sync",
             "cp_kernel_time_ms", "cp_set_stream", "cp_mg_partial_len",
             "cp_mg_halo_len", "cp_mg_halo_pack", "cp_mg_halo_unpack", "cp_mg_state_pack", "cp_mg_state_unpack", "cp_mg_begin", "cp_mg_stage", "cp_mg_end",
-            "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start"]
+            "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start", "cp_singular_values_static"]
 
 BUF_X0, BUF_X1, BUF_P0, BUF_P1, BUF_XTMP = 0, 1, 2, 3, 4
 SEL_ALL, SEL_X_U, SEL_P_Y12, SEL_P_DY, SEL_P_Y2 = 0, 1, 2, 3, 4
@@ -369,3 +370,8 @@ class Engine:
         _chk(lib.cp_kernel_time_ms(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+
+def singular_values_static(device, field_ptr, m, n, k, sv_ptr, stream_ptr=0):
+    """cp_singular_values_static: device pointers as plain ints (e.g. torch.Tensor.data_ptr()); asynchronous on the stream"""
+    _chk(lib.cp_singular_values_static(int(device), C.c_void_p(field_ptr), int(m), int(n), int(k), C.c_void_p(sv_ptr),
+                                       C.c_void_p(stream_ptr or None)))
