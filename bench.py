@@ -25,27 +25,40 @@ ELEMS_ITER = {"tv": 37, "curvature": 31}
 # dominant kernel: NN-TV runs one fused kernel per iteration (k_mf_fused_tv: the whole iteration's 37 elements);
 # NN-curvature runs separate passes, the dual pass (reads x(3)+x_old(3)+p(4)+grad(2)+b(1), writes p(4)) dominates
 ELEMS_DOM = {"tv": 37, "curvature": 17}
-DOM_KERNEL = {"tv": "k_mf_fused_tv<double,false,true,1,256,16>", "curvature": "k_mf_dual<0,1>"}
 
 
-def measured_copy_gbs(dev):
-    """device-to-device copy rate of this box (read + write bytes / time), the practical HBM ceiling next to the
-    vendor peak (SURVEY.md section 8d asks for both)"""
-    import torch
-    n = 1 << 28                                   # 2 GiB per buffer
-    a = torch.empty(n, dtype=torch.float64, device=dev)
-    b = torch.zeros(n, dtype=torch.float64, device=dev)
-    best = 0.0
-    for _ in range(4):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        a.copy_(b)
-        e1.record()
-        e1.synchronize()
-        best = max(best, 2.0 * 8.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-    del a, b
-    torch.cuda.empty_cache()
-    return best
+def dominant_kernel(reg, k, bc, fp32):
+    """name of the dominant kernel as rocprofv3 prints it, derived from what cp_engine.hip launches for this configuration"""
+    S = "float" if fp32 else "double"
+    if reg == "tv":
+        lin = "true" if bc == "linear" else "false"
+        ka = 16 if k > 12 else (12 if k > 8 else (8 if k > 4 else 4))
+        return f"k_mf_fused_tv<{S}, {lin}, {'true' if k == 16 else 'false'}, {ka}, false>"
+    return f"k_mf_dual<{S}, 0, 1>"
+
+
+def measured_copy_gbs(dev_index):
+    """device-to-device copy rate of this box (read + write bytes / time) by the library's own streaming kernel
+    (cp_stream_copy_gbps: nontemporal, grid-stride; 8 bytes per lane = the access shape of the field kernels, and
+    16 bytes per lane): the practical HBM ceiling next to the vendor peak (SURVEY.md section 8d asks for both)"""
+    from ma_amd import engine as E
+    return {"8B_per_lane": E.stream_copy_gbps(dev_index, 1 << 31, 8, 4), "16B_per_lane": E.stream_copy_gbps(dev_index, 1 << 31, 16, 4)}
+
+
+def committed_traffic(kernel, m, n, k):
+    """HBM bytes per launch of `kernel` on this workload from the newest committed rocprofv3 PMC measurement
+    (profiles/*_traffic.json, written by scratch/prof.sh + scratch/traffic_json.py from separate --pmc passes of this very
+    command; corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes). PMC counters cannot be read from inside
+    the run, so this is the last measurement of the same kernel and shape, or None."""
+    try:
+        for f in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
+            doc = json.load(open(os.path.join(ROOT, "profiles", f)))
+            for e in doc.get("entries", []):
+                if e.get("kernel") == kernel and e.get("shape") == [m, n, k]:
+                    return e["hbm_bytes_per_launch"] / 1e9, f
+    except Exception:
+        pass
+    return None, None
 
 
 class _StdoutToStderr:
@@ -276,7 +289,7 @@ def main():
     est, n_power = solver.norm_estimate()
     tau = sigma = math.sqrt(0.99 / est ** 2)                   # :195-196
 
-    copy_gbs = measured_copy_gbs(dev) if rank == 0 else 0.0
+    copy_gbs = measured_copy_gbs(local_rank) if rank == 0 else None
 
     def barrier():
         if world > 1:
@@ -304,15 +317,8 @@ def main():
     times = solver.kernel_times()
 
     if rank == 0:
-        # HBM bytes per launch of the dominant kernel as measured by rocprofv3 PMC passes (profiles/, collected by
-        # scratch/prof.sh on the same workload); null when no matching measurement is committed
-        traffic = None
-        try:
-            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
-            if prof and reg == "tv" and m == 4096 and n == 4096 and k == 16 and world == 1 and not args.fp32:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))["hbm_bytes_per_launch"] / 1e9
-        except Exception:
-            traffic = None
+        kernel = dominant_kernel(reg, k, bc, args.fp32)
+        traffic, traffic_src = committed_traffic(kernel, m, part.nl, k) if world == 1 else (None, None)
         kmn_total = float(k) * m * n
         its = args.steps / dt
         bytes_iter = ELEMS_ITER[reg] * esz * kmn_total
@@ -342,10 +348,19 @@ def main():
                        "achieved_GBps_algorithmic": bytes_iter * its / 1e9,
                        "frac_of_hbm_peak": bytes_iter * its / 1e9 / (HBM_PEAK_GBS * world),
                        "kernel_ms": {kname: (v[0] / v[1]) for kname, v in times.items() if v[1] > 0}},
-            "roofline": {"bound": "hbm", "kernel": DOM_KERNEL[reg], "achieved": achieved,
+            # achieved / frac: ALGORITHMIC bytes of SURVEY.md section 8(d) per launch / measured launch time (the contract's
+            # figure; it exceeds what the kernel moves because fusing removed passes the survey charges for).
+            # hbm_achieved / hbm_frac: what the memory system did -- bytes per launch by the PMC counters (traffic) / the
+            # same launch time.
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
-                         "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)"},
+                         "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, KiB units)",
+                         "traffic_source": traffic_src,
+                         "algorithmic_GB_per_launch": dual_bytes / 1e9,
+                         "hbm_achieved": (traffic / dual_avg_s) if (traffic and dual_avg_s > 0) else None,
+                         "hbm_frac": (traffic / dual_avg_s / HBM_PEAK_GBS) if (traffic and dual_avg_s > 0) else None,
+                         "measured_copy_GBps": copy_gbs,
+                         "hbm_frac_of_measured_copy": (traffic / dual_avg_s / max(copy_gbs.values())) if (traffic and dual_avg_s > 0 and copy_gbs) else None},
         }
         if not args.no_cpu_baseline:
             csize, citers = (args.cpu_size, args.cpu_iters) if reg == "tv" else (min(args.cpu_size, 256), min(args.cpu_iters, 6))

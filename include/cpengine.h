@@ -197,6 +197,10 @@ int cp_iterate_steps(cp_handle h, int32_t iters);
 int cp_iterate_end(cp_handle h);
 int cp_sync(cp_handle h);
 int cp_kernel_time_ms(cp_handle h, const char *pass, double *ms, int64_t *launches);
+/* device-to-device streaming copy rate of this GPU in GB/s (read + write bytes / time, best of `repeats` passes over
+ * two buffers of `bytes` each, 8 or 16 bytes per lane, nontemporal): the practical HBM ceiling next to the data sheet's
+ * peak. Allocates and frees its own buffers. */
+int cp_stream_copy_gbps(int32_t device, int64_t bytes, int32_t lane_bytes, int32_t repeats, double *gbps);
 
 /* --- row-slab multi-GPU hooks (no counterpart in the reference; NN-TV model) -----------------------
  * One process per GPU, each with a handle created with n = owned columns, n_global, j_offset. The
@@ -230,7 +234,8 @@ int cp_mg_halo_unpack(cp_handle h, int buf, int sel, int side, const double *dev
  * (No counterpart in the reference: its matrices are never partitioned.)                                   */
 int cp_mg_state_pack(cp_handle h, int xbuf, int pbuf, double *dev_to_left, double *dev_to_right);
 int cp_mg_state_unpack(cp_handle h, int xbuf, int pbuf, const double *dev_from_right, const double *dev_from_left);
-int cp_mg_begin(cp_handle h, double theta, double tau, double sigma);
+/* max_iters: capacity of the history (rows 0..max_iters) for this run */
+int cp_mg_begin(cp_handle h, double theta, double tau, double sigma, int32_t max_iters);
 /* dev_buf: stage output (own reduced partials) or input (world gathered partial vectors)               */
 int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, int32_t world, double scale,
                 int32_t check_stop, double tol);

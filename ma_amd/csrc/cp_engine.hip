@@ -81,9 +81,7 @@ struct cp_engine {
     bool time_all = false;   // CP_TUNE_TIME_ALL=1: HIP events around the small kernels of the fused paths too (each pair of
                              // events costs a few microseconds of stream time; by default only the dominant kernel is timed)
     bool pw_split = false;   // tuning aid (CP_TUNE_PW_SPLIT=1): pairwise models on the split passes instead of k_pw_fused
-    int fused_nt = CP_BLOCK;   // threads per workgroup of k_mf_fused_tv (512: CP_TUNE_FUSED_THREADS, with tile width 2)
-    int fused_tw = 1;    // image columns per workgroup tile of k_mf_fused_tv
-    int fused_ka = 1;    // use the K <= 8 / K <= 12 instantiations of k_mf_fused_tv (CP_TUNE_FUSED_KA=0: always 16)
+    int fused_ka = 1;    // use the K <= 4 / 8 / 12 instantiations of k_mf_fused_tv (CP_TUNE_FUSED_KA=0: always 16)
     int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU resident: two LDS tiles per wave)
     bool linearized = false, has_nu = false, has_images = false;
     hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless cp_set_stream)
@@ -199,6 +197,8 @@ static int ensure_hist(cp_engine *h, int rows) {
     const size_t bytes = sizeof(double) * (size_t)rows * h->hcols * h->batch;
     HIPCHK(hipMalloc(&h->hist_p, bytes));
     HIPCHK(hipMalloc(&h->hist_d, bytes));
+    HIPCHK(hipMemsetAsync(h->hist_p, 0, bytes, h->stream));
+    HIPCHK(hipMemsetAsync(h->hist_d, 0, bytes, h->stream));
     h->hist_rows = rows;
     return CP_OK;
 }
@@ -266,6 +266,9 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
                 CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg slab [%d, %d) outside [0, %d)", d.j_offset, d.j_offset + d.n, d.n_global);
         }
     }
+    // the field kernels address a field with 32-bit byte offsets (ldo / sto, cp_device.cuh) and count pixels in int
+    if ((long long)d.m * ((long long)d.n + 2) * (long long)sizeof(double) >= (1LL << 32))
+        CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported a field of %d x %d doubles reaches 4 GiB (32-bit offsets inside a field)", d.m, d.n);
     cp_engine *h = new cp_engine();
     h->d = d;
     if (h->d.batch < 1) h->d.batch = 1;
@@ -331,19 +334,14 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         HIPCHK(hipMalloc(&h->img, sizeof(double) * imgN));
         if (!mf && h->gt != GT_SAD_DEN) HIPCHK(hipMalloc(&h->imgR, sizeof(double) * imgN));
         h->nblk = grid_for(h);
-        // k_mf_fused_tv: up to 4096 workgroups (512 are resident: 2 per CU), chunks strided by the grid. Measured at
-        // 4096^2 x 16: 12.1 ms with 512 workgroups, 11.4 ms with 4096, 11.3 ms with one chunk per workgroup (65536).
-        // tile width 1 (256 rows x 1 column) measured best at 4096^2 x 16: 11.6-11.9 ms vs 11.7 (2) and 12.0 (4); wider
-        // tiles turn the i+1 spill-over line of every wave into a miss of its own XCD's L2
-        h->fused_tw = 1;
-        if (const char *ev = getenv("CP_TUNE_FUSED_TW")) h->fused_tw = (atoi(ev) == 4) ? 4 : (atoi(ev) == 2 ? 2 : 1);   // tuning knobs
-        if (const char *ev = getenv("CP_TUNE_FUSED_THREADS")) { if (atoi(ev) == 512) { h->fused_nt = 512; h->fused_tw = 2; } }
-        h->nblk_fused = std::max(1, std::min(fused_tiles(h->m, h->nl, h->fused_tw, h->fused_nt), CP_FUSED_MAXGRID));
-        if (d.flags & CP_FLAG_MFNN_NORM21) { h->fused_nt = CP_BLOCK; h->fused_tw = 1; h->nblk_fused = std::max(1, std::min(fused_tiles(h->m, h->nl, 1, CP_BLOCK), CP_FUSED_MAXGRID)); }
+        // k_mf_fused_tv: one workgroup task per (part of a column, group of 4 columns), up to 4096 workgroups (512 are
+        // resident: 2 per CU), tasks strided by the grid; a multiple of 8 workgroups keeps a part on one XCD. Measured at
+        // 4096^2 x 16: 10.4-10.7 ms for grids of 4096, 2048, 1024; 10.8 ms for 512 (persistent).
+        h->nblk_fused = (int)std::min<long long>((fused2_tasks(h->m, h->nl) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         if (const char *ev = getenv("CP_TUNE_FUSED_KA")) h->fused_ka = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_PW_SPLIT")) h->pw_split = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_TIME_ALL")) h->time_all = atoi(ev) != 0;
-        if (const char *ev = getenv("CP_TUNE_FUSED_GRID")) h->nblk_fused = std::max(1, std::min(h->nblk_fused, atoi(ev)));
+        if (const char *ev = getenv("CP_TUNE_FUSED_GRID")) h->nblk_fused = std::max(8, std::min(h->nblk_fused, atoi(ev) / 8 * 8));
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
             HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
@@ -835,33 +833,23 @@ static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int
 }
 
 // one launch of k_mf_fused_tv: x_{n-1} in xp, x_n written to xc; y_n in pc, y_{n+1} written to pn
-template <typename S, int TW, int NT = CP_BLOCK>
-static void launch_fused_tw(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
-                            const double *W) {
-    auto kern = (h->d.bc == CP_BC_LINEAR)
-                    ? (h->K == CP_KMAX ? k_mf_fused_tv<S, true, true, TW, NT> : k_mf_fused_tv<S, true, false, TW, NT>)
-                    : (h->K == CP_KMAX ? k_mf_fused_tv<S, false, true, TW, NT> : k_mf_fused_tv<S, false, false, TW, NT>);
-    if (TW == 1 && NT == CP_BLOCK && h->K <= 12 && h->fused_ka) {   // production tile shape: image arrays of 4, 8 or 12 instead of 16
-        const bool lin = (h->d.bc == CP_BC_LINEAR);
-        if (h->K <= 4) kern = lin ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, 4> : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, 4>;
-        else if (h->K <= 8) kern = lin ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, 8> : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, 8>;
-        else kern = lin ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, 12> : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, 12>;
-    }
-    if constexpr (TW == 1 && NT == CP_BLOCK) {   // (the tile-shape tuning knobs are ignored in this mode, see cp_create)
-        if (P.norm21)   // single-level driver (NNE/mf_nn_tv_registration_no_ref.m): one instantiation per boundary condition
-            kern = (h->d.bc == CP_BC_LINEAR) ? k_mf_fused_tv<S, true, false, 1, CP_BLOCK, CP_KMAX, true>
-                                              : k_mf_fused_tv<S, false, false, 1, CP_BLOCK, CP_KMAX, true>;
-    }
-    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(NT), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
+template <typename S>
+static void launch_fused_t(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
+                           const double *W) {
+    const bool lin = (h->d.bc == CP_BC_LINEAR);
+    auto kern = lin ? k_mf_fused_tv<S, true, false> : k_mf_fused_tv<S, false, false>;
+    if (P.norm21) kern = lin ? k_mf_fused_tv<S, true, false, CP_KMAX, true> : k_mf_fused_tv<S, false, false, CP_KMAX, true>;   // single-level driver
+    else if (h->K == CP_KMAX) kern = lin ? k_mf_fused_tv<S, true, true> : k_mf_fused_tv<S, false, true>;
+    else if (h->K <= 4 && h->fused_ka) kern = lin ? k_mf_fused_tv<S, true, false, 4> : k_mf_fused_tv<S, false, false, 4>;
+    else if (h->K <= 8 && h->fused_ka) kern = lin ? k_mf_fused_tv<S, true, false, 8> : k_mf_fused_tv<S, false, false, 8>;
+    else if (h->K <= 12 && h->fused_ka) kern = lin ? k_mf_fused_tv<S, true, false, 12> : k_mf_fused_tv<S, false, false, 12>;
+    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
                        (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
 }
 static void launch_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
                          const double *W) {
-    if (h->fused_nt == 512 && !h->fp32) launch_fused_tw<double, 2, 512>(h, P, xp, xc, pc, pn, W);
-    else if (h->fp32) launch_fused_tw<float, 1>(h, P, xp, xc, pc, pn, W);   // the tile-width knob is an fp64 tuning aid
-    else if (h->fused_tw == 1) launch_fused_tw<double, 1>(h, P, xp, xc, pc, pn, W);
-    else if (h->fused_tw == 2) launch_fused_tw<double, 2>(h, P, xp, xc, pc, pn, W);
-    else launch_fused_tw<double, 4>(h, P, xp, xc, pc, pn, W);
+    if (h->fp32) launch_fused_t<float>(h, P, xp, xc, pc, pn, W);
+    else launch_fused_t<double>(h, P, xp, xc, pc, pn, W);
 }
 
 // ---- fused NN-TV path: F_0 = dual step 1 alone, then one k_mf_fused_tv + k_mf_efused per iteration -------------
@@ -1633,13 +1621,16 @@ extern "C" int cp_mg_state_unpack(cp_handle h, int xbuf, int pbuf, const double 
     return mg_state(h, xbuf, pbuf, 0, (double *)dev_from_right, (double *)dev_from_left);
 }
 
-extern "C" int cp_mg_begin(cp_handle h, double theta, double tau, double sigma) {
+extern "C" int cp_mg_begin(cp_handle h, double theta, double tau, double sigma, int32_t max_iters) {
     if (!h || !h->mf || h->var) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_begin needs an mf_nn handle");
     HIPCHK(hipSetDevice(h->d.device));
     CP_NOT_ITERATING(h);
     if (!h->linearized || !h->has_nu) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_begin before linearize / set_nu");
     h->mg_theta = theta; h->mg_tau = tau; h->mg_sigma = sigma;
-    CPCHK(ensure_hist(h, 4096));
+    if (max_iters < 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg max_iters < 0");
+    CPCHK(ensure_hist(h, max_iters + 2));
+    HIPCHK(hipMemsetAsync(h->hist_p, 0, sizeof(double) * (size_t)h->hist_rows * h->hcols, h->stream));
+    HIPCHK(hipMemsetAsync(h->hist_d, 0, sizeof(double) * (size_t)h->hist_rows * h->hcols, h->stream));
     h->profile = true;     // per-launch HIP events of the fused kernel (cp_kernel_time_ms)
     h->it_n = 0;
     h->it_mg = true;
@@ -1755,6 +1746,8 @@ extern "C" int cp_mg_end(cp_handle h, int32_t iterations) {
     if (!h || !h->mf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_end");
     HIPCHK(hipSetDevice(h->d.device));
     if (!(h->it_n >= 0 && h->it_mg)) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_end without cp_mg_begin");
+    if (iterations < 0 || iterations + 1 > h->hist_rows)
+        CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_end(%d) beyond the %d history rows of cp_mg_begin", iterations, h->hist_rows);
     const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
     int zero = 0;
     HIPCHK(hipMemcpyAsync(h->ctrl, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -1824,6 +1817,65 @@ extern "C" int cp_mg_power_start(cp_handle h, double *local_sumsq) {
     for (int bI = 0; bI < h->nblk; ++bI) s += hp[(size_t)bI * CP_PSTRIDE];
     *local_sumsq = s;
     return CP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming copy: the practical HBM ceiling of this box next to the 8 TB/s of the data sheet (bench.py's
+// roofline.measured_copy_GBps). One element of VEC doubles per lane and step (8 or 16 bytes per lane), grid-stride,
+// nontemporal on both sides -- the access shape of the field kernels (8 B/lane) and the widest one (16 B/lane).
+template <int VEC>
+__global__ __launch_bounds__(CP_BLOCK) void k_stream_copy(size_t n, const double *__restrict__ src, double *__restrict__ dst) {
+    typedef double vec_t __attribute__((ext_vector_type(VEC)));
+    const vec_t *s = reinterpret_cast<const vec_t *>(src);
+    vec_t *d = reinterpret_cast<vec_t *>(dst);
+    const size_t nv = n / VEC, stride = (size_t)gridDim.x * CP_BLOCK;
+    for (size_t q = (size_t)blockIdx.x * CP_BLOCK + threadIdx.x; q < nv; q += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(s + q), d + q);
+}
+template <>
+__global__ __launch_bounds__(CP_BLOCK) void k_stream_copy<1>(size_t n, const double *__restrict__ src, double *__restrict__ dst) {
+    const size_t stride = (size_t)gridDim.x * CP_BLOCK;
+    for (size_t q = (size_t)blockIdx.x * CP_BLOCK + threadIdx.x; q < n; q += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + q), dst + q);
+}
+
+extern "C" int cp_stream_copy_gbps(int32_t device, int64_t bytes, int32_t lane_bytes, int32_t repeats, double *gbps) {
+    if (!gbps || bytes < (1 << 20) || repeats < 1 || (lane_bytes != 8 && lane_bytes != 16))
+        CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_stream_copy_gbps(bytes >= 1 MiB, lane_bytes 8 | 16, repeats >= 1)");
+    HIPCHK(hipSetDevice(device));
+    const size_t n = (size_t)bytes / 16 * 2;   // doubles, a multiple of 2
+    double *a = nullptr, *bq = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = CP_OK;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc(&a, n * sizeof(double)));
+        HIPCHK(hipMalloc(&bq, n * sizeof(double)));
+        HIPCHK(hipMemset(a, 0, n * sizeof(double)));
+        HIPCHK(hipMemset(bq, 0, n * sizeof(double)));
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        double best = 0.0;
+        const int grid = 256 * 16;
+        for (int r = 0; r < repeats + 1; ++r) {   // the first pass warms up
+            HIPCHK(hipEventRecord(e0, nullptr));
+            if (lane_bytes == 16) hipLaunchKernelGGL((k_stream_copy<2>), dim3(grid), dim3(CP_BLOCK), 0, nullptr, n, a, bq);
+            else hipLaunchKernelGGL((k_stream_copy<1>), dim3(grid), dim3(CP_BLOCK), 0, nullptr, n, a, bq);
+            HIPCHK(hipEventRecord(e1, nullptr));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0 && ms > 0.f) best = std::max(best, 2.0 * (double)n * sizeof(double) / (ms * 1e-3) / 1e9);
+        }
+        HIPCHK(hipGetLastError());
+        *gbps = best;
+        return CP_OK;
+    };
+    rc = body();
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (a) hipFree(a);
+    if (bq) hipFree(bq);
+    return rc;
 }
 
 // ================================================================================================

@@ -70,37 +70,53 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
     wy = -vuy;
 }
 
-// Tiles: a workgroup handles TW adjacent image columns x 256/TW rows per step (TW = 4: one column segment of 64 rows per
-// wave). Wider tiles serve the j+1 neighbour loads of waves 0..TW-2 from the next wave's own loads, but make the i+1
-// spill-over line of every wave a miss in the XCD's L2; TW = 1 measured best (see cp_create).
-__host__ __device__ inline int fused_tiles(int m, int nl, int tw, int nt = CP_BLOCK) { return ((m + nt / tw - 1) / (nt / tw)) * ((nl + tw - 1) / tw); }
+// ---- k_mf_fused_tv: organised by wavefront -----------------------------------------------------------------------------
+// A wavefront owns one image column and marches DOWN it in aligned segments of 64 rows (a "part" of `steps` segments per
+// task), so that the (i+1, j) neighbour of every row is an own-pixel result that already exists: lane+1's in the same
+// step (cross-lane shift), and for lane 63 the value lane 0 produced one step earlier, handed over through 32 doubles of
+// LDS per image. The 13 loads per image of the recomputation at (i+1, j) -- a third of the kernel's load instructions and
+// L2 requests, and the spill-over lines that belong to another XCD -- are gone; only the first step of a part that does
+// not start at the image's last row recomputes that one neighbour, in lane 63 alone. The four waves of a workgroup take
+// four adjacent columns and run free (the tiles are wave-private: the Gram steps need only the ordering of the wave's own
+// LDS instructions, wave_lds_sync, not a workgroup barrier; they meet once, for the partial row), so the (i, j+1) loads of
+// waves 0..2 are the lines the next wave streams at the same moment. Tasks (part, column group) are dealt so that a part
+// stays on one XCD (8 parts per column when there are at least 8 segments; gridDim.x % 8 == 0) and the next column
+// group's task -- whose own loads are wave 3's (i, j+1) loads -- is the next workgroup of that XCD.
+struct Fused2Geom { int nseg, parts, steps; };
+__host__ __device__ inline Fused2Geom fused2_geom(int m) {
+    Fused2Geom G;
+    G.nseg = (m + 63) >> 6;
+    G.parts = G.nseg < 8 ? G.nseg : 8;
+    G.steps = (G.nseg + G.parts - 1) / G.parts;
+    G.parts = (G.nseg + G.steps - 1) / G.steps;   // drop parts that would be empty
+    return G;
+}
+__host__ __device__ inline long long fused2_tasks(int m, int nl) { return (long long)fused2_geom(m).parts * ((nl + CP_WAVES - 1) / CP_WAVES); }
 
 // KA = extent of the per-pixel image arrays (4, 8, 12 or 16 >= K): phase 1 loads, multiplies by W and stores KA images, so
-// K = 10 does not pay for 16 (the Gram tiles stay 16 x 16, zero padded).
-// NT = threads per workgroup: 256 (2 workgroups per CU) or 512 (one workgroup per CU, e.g. TW = 2: two adjacent columns
-// of 256 rows side by side, so that half of the j+1 neighbour loads are lines the other half of the workgroup streams)
-// N21: F2 = mu*||.||_{2,1} (NNE/norm21.m, the single-level driver) instead of the pointwise 2x2 nuclear norm
-template <typename S, bool LINEAR, bool FULLK, int TW, int NT = CP_BLOCK, int KA = CP_KMAX, bool N21 = false>
-__global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParams P, const S *__restrict__ xo,
-                                                             S *__restrict__ xn, const S *__restrict__ pin,
-                                                             S *__restrict__ pout, const S *__restrict__ g,
-                                                             const S *__restrict__ b, const double *__restrict__ W,
-                                                             const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
-    constexpr int NWV = NT / 64;
+// K = 10 does not pay for 16 (the Gram tiles stay 16 x 16, zero padded). N21: F2 = mu*||.||_{2,1} (NNE/norm21.m, the
+// single-level driver) instead of the pointwise 2x2 nuclear norm.
+template <typename S, bool LINEAR, bool FULLK, int KA = CP_KMAX, bool N21 = false>
+__global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
+                                                              const S *__restrict__ pin, S *__restrict__ pout,
+                                                              const S *__restrict__ g, const S *__restrict__ b,
+                                                              const double *__restrict__ W,
+                                                              const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
+    constexpr int NWV = CP_WAVES;
     __shared__ double tiles[NWV * 2 * 16 * CP_TS];
     __shared__ double Wl[CP_KMAX * CP_KMAX];
-    // the control words and W are requested together: one global round trip before the first tile instead of three
-    // (it is a visible part of the 40 us a launch takes on the coarse pyramid levels)
+    __shared__ double carry_all[NWV * 2 * CP_KMAX * 4];   // [wave][step parity][image][ux, uy, ux_old, uy_old] of lane 0
     const int stopped = ctrl->stop;
     const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *tileA = tiles + wave * 2 * 16 * CP_TS, *tileB = tileA + 16 * CP_TS;
+    double *carry = carry_all + wave * 2 * CP_KMAX * 4;
     const int K = P.K, m = P.m;
     const size_t fs = (size_t)P.fs;
     const bool linear = LINEAR;
     stage_W(W, Wl);
     if (stopped) return;
-    if (KA < CP_KMAX) {   // tile rows the image loops never touch: zeros for the 16 x 16 Gram tiles
+    if (KA < CP_KMAX) {
         for (int k = KA; k < CP_KMAX; ++k) tileA[k * CP_TS + lane] = 0.0;
     }
     __syncthreads();
@@ -120,169 +136,188 @@ __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParam
     maxs[DM_Y1 - CP_NSUM] = 0.0; maxs[DM_S1 - CP_NSUM] = 0.0; maxs[PM_VL - CP_NSUM] = 0.0;
     double4_t acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 
-    constexpr int TH = NT / TW;
-    const int tiles_i = (m + TH - 1) / TH, ntiles = tiles_i * ((P.nl + TW - 1) / TW);
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int tj = t / tiles_i, ti = t - tj * tiles_i;
-        const int ii = ti * TH + (tid % TH), jj = tj * TW + (tid / TH);
-        const bool valid = (ii < m) && (jj < P.nl);
-        const int i = min(ii, m - 1), j = min(jj, P.nl - 1);   // lanes past the end redo an edge pixel, nothing is stored
-        const unsigned off = ES * (unsigned)((j + 1) * m + i);   // byte offset of (i, j) inside a field (halo column first)
+    const Fused2Geom GM = fused2_geom(m);
+    const int ntasks = GM.parts * ((P.nl + NWV - 1) / NWV);
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const int cg = task / GM.parts, pt = task - cg * GM.parts;
+        const int j = cg * NWV + wave;
+        if (j >= P.nl) continue;                                   // wave-uniform
+        const int seg_lo = pt * GM.steps, seg_hi = min(seg_lo + GM.steps, GM.nseg) - 1;
         const int jg = P.j_off + j;
-        const bool last_i = (i == m - 1), last_j = (jg == P.n_global - 1);
+        const bool last_j = (jg == P.n_global - 1);
+        const int oj = (last_j && LINEAR) ? -1 : 1;
+        for (int sg = seg_hi; sg >= seg_lo; --sg) {
+            const int par = (seg_hi - sg) & 1;                     // carry slot written by this step
+            const int ii = sg * 64 + lane;
+            const bool valid = ii < m;
+            const int i = min(ii, m - 1);                          // lanes past the end redo the last row, nothing is stored
+            const unsigned off = ES * (unsigned)((j + 1) * m + i);
+            const bool last_i = (i == m - 1);
 
-        // ---- phase 1: everything that couples the K images of this pixel --------------------------------
-        // all 3K loads are issued up front (image index clamped for K < 16; FULLK folds the guards away)
-        double a[KA], Lr[KA], y1v[KA];
-        {
-            double t3[KA];
+            // ---- phase 1: everything that couples the K images of this pixel (as in k_mf_fused_tv) ---------------------
+            double a[KA], Lr[KA], y1v[KA];
+            {
+                double t3[KA];
+#pragma unroll
+                for (int k = 0; k < KA; ++k) {
+                    const int kk = (FULLK || k < K) ? k : K - 1;
+                    t3[k] = ldo_stream(y3in + (size_t)kk * fs, off);
+                    y1v[k] = ldo(pin + (size_t)kk * fs, off);
+                    Lr[k] = ldo_stream(Lin + (size_t)kk * fs, off);
+                }
+#pragma unroll
+                for (int kp = 0; kp < KA; ++kp) a[kp] = 0.0;
+#pragma unroll
+                for (int k = 0; k < KA; ++k) {
+                    const double t = (FULLK || k < K) ? t3[k] : 0.0;
+#pragma unroll
+                    for (int kp = 0; kp < KA; ++kp) a[kp] = fma(t, Wl[k * CP_KMAX + kp], a[kp]);
+                }
+            }
+            double s3 = 0.0;
+#pragma unroll
+            for (int kp = 0; kp < KA; ++kp) s3 += a[kp];
+            const double mean3 = s3 * P.invK;
+            double sumL = 0.0, sumLb = 0.0, vLmax = 0.0;
 #pragma unroll
             for (int k = 0; k < KA; ++k) {
-                const int kk = (FULLK || k < K) ? k : K - 1;
-                t3[k] = ldo_stream(y3in + (size_t)kk * fs, off);
-                y1v[k] = ldo(pin + (size_t)kk * fs, off);
-                Lr[k] = ldo_stream(Lin + (size_t)kk * fs, off);
+                const bool act = FULLK || (k < K);
+                const double Lo = Lr[k];
+                const double vL = y1v[k] + (a[k] - mean3);
+                const double Ln = rnd<S>(Lo - tau * vL);
+                const double Lb = Ln + theta * (Ln - Lo);
+                vLmax = fmax(vLmax, act ? fabs(vL) : 0.0);
+                Lr[k] = act ? Ln : 0.0;
+                a[k] = a[k] + sigma * Lb;
+                sumL += act ? Ln : 0.0;
+                sumLb += act ? Lb : 0.0;
+                tileB[k * CP_TS + lane] = Lb;
             }
-#pragma unroll
-            for (int kp = 0; kp < KA; ++kp) a[kp] = 0.0;
+            if (valid) maxs[PM_VL - CP_NSUM] = fmax(maxs[PM_VL - CP_NSUM], vLmax);
+            const double smb = sigma * (sumLb * P.invK), mL = sumL * P.invK;
 #pragma unroll
             for (int k = 0; k < KA; ++k) {
-                const double t = (FULLK || k < K) ? t3[k] : 0.0;
-#pragma unroll
-                for (int kp = 0; kp < KA; ++kp) a[kp] = fma(t, Wl[k * CP_KMAX + kp], a[kp]);   // y3_n = y3~_n * W_n
+                const bool act = FULLK || (k < K);
+                const double v = (valid && act) ? rnd<S>(a[k] - smb) : 0.0;
+                tileA[k * CP_TS + lane] = v;
+                if (valid && act) {
+                    sto(y3out + (size_t)k * fs, off, v);
+                    sto(Lout + (size_t)k * fs, off, Lr[k]);
+                }
             }
-        }
-        double s3 = 0.0;
+            wave_lds_sync();
+            gram_tile_accum(tileA, acc1);
+            wave_lds_sync();
 #pragma unroll
-        for (int kp = 0; kp < KA; ++kp) s3 += a[kp];
-        const double mean3 = s3 * P.invK;
-        double sumL = 0.0, sumLb = 0.0, vLmax = 0.0;
+            for (int k = 0; k < KA; ++k)
+                tileA[k * CP_TS + lane] = (valid && (FULLK || k < K)) ? Lr[k] - mL : 0.0;
+            wave_lds_sync();
+            gram_tile_accum(tileA, acc2);
+            wave_lds_sync();
 #pragma unroll
-        for (int k = 0; k < KA; ++k) {
-            const bool act = FULLK || (k < K);
-            const double Lo = Lr[k];
-            const double vL = y1v[k] + (a[k] - mean3);               // (A'y)_L = y1 + B*y3
-            const double Ln = rnd<S>(Lo - tau * vL);                  // zero_function prox = identity
-            const double Lb = Ln + theta * (Ln - Lo);                 // chambolle_pock.m:179
-            vLmax = fmax(vLmax, act ? fabs(vL) : 0.0);                // NNE/zero_function.m:32
-            Lr[k] = act ? Ln : 0.0;
-            a[k] = a[k] + sigma * Lb;                                 // y3_n + sigma*Lbar (mean removed below)
-            sumL += act ? Ln : 0.0;
-            sumLb += act ? Lb : 0.0;
-            tileB[k * CP_TS + lane] = Lb;
-        }
-        if (valid) maxs[PM_VL - CP_NSUM] = fmax(maxs[PM_VL - CP_NSUM], vLmax);
-        const double smb = sigma * (sumLb * P.invK), mL = sumL * P.invK;
-#pragma unroll
-        for (int k = 0; k < KA; ++k) {
-            const bool act = FULLK || (k < K);
-            const double v = (valid && act) ? rnd<S>(a[k] - smb) : 0.0;   // y3~_{n+1} = y3_n + sigma*B*Lbar
-            tileA[k * CP_TS + lane] = v;
-            if (valid && act) {
-                sto(y3out + (size_t)k * fs, off, v);
-                sto(Lout + (size_t)k * fs, off, Lr[k]);
-            }
-        }
-        __syncthreads();
-        gram_tile_accum(tileA, acc1);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < KA; ++k)
-            tileA[k * CP_TS + lane] = (valid && (FULLK || k < K)) ? Lr[k] - mL : 0.0;   // B*L_n
-        __syncthreads();
-        gram_tile_accum(tileA, acc2);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < KA; ++k) tileA[k * CP_TS + lane] = Lr[k];
+            for (int k = 0; k < KA; ++k) tileA[k * CP_TS + lane] = Lr[k];
 
-        // ---- phase 2: per image: displacement part of the primal step (own pixel + 2 neighbours), dual step ----
-        // neighbours along i and j ("previous" instead of "next" on a linear boundary row; unused otherwise)
-        const int oi = (last_i && LINEAR) ? -1 : 1, oj = (last_j && LINEAR) ? -1 : 1;
-        const PixOff p0 = {off, off - mb};
-        const PixOff pi = {oi > 0 ? off + ES : off - ES, (oi > 0 ? off + ES : off - ES) - mb};
-        const PixOff pj = {oj > 0 ? off + mb : off - mb, oj > 0 ? off : off - 2u * mb};
-        const double vmask = valid ? 1.0 : 0.0;
-        for (int k = 0; k < K; ++k) {
-            const S *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
-            const S *gxk = g + 2 * (size_t)k * fs, *uxk = xo + 2 * (size_t)k * fs;
-            const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
-            double ux, uy, uxo_, uyo_, wx, wy, uxi, uyi, oi0, oi1, uxj, uyj, oj0, oj1, wd0, wd1;
-            primal_u_at<S, LINEAR>(P, i, jg, p0, fsb, y1k, y2k, gxk, uxk, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
-            primal_u_at<S, LINEAR>(P, i + oi, jg, pi, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
-            primal_u_at<S, LINEAR>(P, i, jg + oj, pj, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
-            const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
-            const double bb = ldo_stream(b + (size_t)k * fs, off);
-            const double y1 = ldo(y1k, off);
-            const double v0 = ldo(y2k, off), v1 = ldo(y2k + fs, off), v2 = ldo(y2k + 2 * fs, off), v3 = ldo(y2k + 3 * fs, off);
-            S *uxo_k = xn + 2 * (size_t)k * fs;
+            // ---- phase 2: per image: primal step at the own pixel and at (i, j+1); (i +- 1, j) from a neighbour lane ------
+            // where the i-neighbour's own-pixel result comes from: lane +- 1 of this step; for lane 63 the hand-over of the
+            // previous step (the segment above); recomputed (lane-masked) only where neither exists
+            const int oi = (last_i && LINEAR) ? -1 : 1;
+            const int nb_lane = lane + oi;
+            const bool want = valid && (LINEAR || !last_i);          // the neighbour's value is used at all
+            const bool from_carry = want && nb_lane == 64 && sg < seg_hi;
+            const bool recompute = want && (nb_lane < 0 || nb_lane > 63) && !from_carry;
+            const bool any_rc = __any(recompute);                    // wave-uniform: first step of a part / m % 64 == 1 with linear rows
+            const PixOff p0 = {off, off - mb};
+            const PixOff pj = {oj > 0 ? off + mb : off - mb, oj > 0 ? off : off - 2u * mb};
+            const PixOff pi = {oi > 0 ? off + ES : off - ES, (oi > 0 ? off + ES : off - ES) - mb};
+            const double *cin = carry + (par ^ 1) * CP_KMAX * 4;
+            double *cout_ = carry + par * CP_KMAX * 4;
+            const double vmask = valid ? 1.0 : 0.0;
+            for (int k = 0; k < K; ++k) {
+                const S *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
+                const S *gxk = g + 2 * (size_t)k * fs, *uxk = xo + 2 * (size_t)k * fs;
+                const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
+                double ux, uy, uxo_, uyo_, wx, wy, uxj, uyj, oj0, oj1, wd0, wd1;
+                primal_u_at<S, LINEAR>(P, i, jg, p0, fsb, y1k, y2k, gxk, uxk, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
+                primal_u_at<S, LINEAR>(P, i, jg + oj, pj, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
+                const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
+                const double bb = ldo_stream(b + (size_t)k * fs, off);
+                const double y1 = ldo(y1k, off);
+                const double v0 = ldo(y2k, off), v1 = ldo(y2k + fs, off), v2 = ldo(y2k + 2 * fs, off), v3 = ldo(y2k + 3 * fs, off);
+                S *uxo_k = xn + 2 * (size_t)k * fs;
+                // bitwise what a recomputation at (i +- 1, j) would give
+                double uxi = __shfl(ux, nb_lane), uyi = __shfl(uy, nb_lane);
+                double oi0 = __shfl(uxo_, nb_lane), oi1 = __shfl(uyo_, nb_lane);
+                if (from_carry) { uxi = cin[4 * k]; uyi = cin[4 * k + 1]; oi0 = cin[4 * k + 2]; oi1 = cin[4 * k + 3]; }
+                if (any_rc) {
+                    if (recompute)
+                        primal_u_at<S, LINEAR>(P, i + oi, jg, pi, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
+                }
+                if (lane == 0) { cout_[4 * k] = ux; cout_[4 * k + 1] = uy; cout_[4 * k + 2] = uxo_; cout_[4 * k + 3] = uyo_; }
 
-            if (valid) {
-                sto(uxo_k, off, ux);
-                sto(uxo_k + fs, off, uy);
-                // G*(-A'y_n): NNE/mean_zero_indicator.m:78-84
-                maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], wx);
-                maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], -wx);
-                maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], wy);
-                maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], -wy);
-            }
-            sums[PS_WX] += vmask * wx;
-            const double uxb = ux + theta * (ux - uxo_), uyb = uy + theta * (uy - uyo_);
-            const double uxbi = uxi + theta * (uxi - oi0), uybi = uyi + theta * (uyi - oi1);
-            const double uxbj = uxj + theta * (uxj - oj0), uybj = uyj + theta * (uyj - oj1);
+                if (valid) {
+                    sto(uxo_k, off, ux);
+                    sto(uxo_k + fs, off, uy);
+                    maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], wx);
+                    maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], -wx);
+                    maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], wy);
+                    maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], -wy);
+                }
+                sums[PS_WX] += vmask * wx;
+                const double uxb = ux + theta * (ux - uxo_), uyb = uy + theta * (uy - uyo_);
+                const double uxbi = uxi + theta * (uxi - oi0), uybi = uyi + theta * (uyi - oi1);
+                const double uxbj = uxj + theta * (uxj - oj0), uybj = uyj + theta * (uyj - oj1);
 
-            // ---- y1: SAD* (identical to k_mf_dual) -------------------------------------------------
-            const double r_cur = -(gx * ux + gy * uy) + Lc;
-            const double r_bar = -(gx * uxb + gy * uyb) + Lbar;
-            sums[DS_F1] += vmask * fabs(r_cur - bb);                           // NNE/SAD.m:54
-            const double yt = y1 + sigma * r_bar;
-            const double Ls = yt * inv_sigma, thr = inv_sigma * P.mu1, dd = Ls - bb;
-            const double prox = (dd > thr) ? (Ls - thr) : ((dd < -thr) ? (Ls + thr) : bb);   // :42-49
-            const double y1n = rnd<S>(yt - sigma * prox);                      // :71-72
-            sums[DS_F1S] += vmask * (y1n * bb);                                // :83
-            sums[DS_SGX] += vmask * (gx * y1n);
-            sums[DS_SGY] += vmask * (gy * y1n);
+                const double r_cur = -(gx * ux + gy * uy) + Lc;
+                const double r_bar = -(gx * uxb + gy * uyb) + Lbar;
+                sums[DS_F1] += vmask * fabs(r_cur - bb);
+                const double yt = y1 + sigma * r_bar;
+                const double Ls = yt * inv_sigma, thr = inv_sigma * P.mu1, dd = Ls - bb;
+                const double prox = (dd > thr) ? (Ls - thr) : ((dd < -thr) ? (Ls + thr) : bb);
+                const double y1n = rnd<S>(yt - sigma * prox);
+                sums[DS_F1S] += vmask * (y1n * bb);
+                sums[DS_SGX] += vmask * (gx * y1n);
+                sums[DS_SGY] += vmask * (gy * y1n);
 
-            // ---- y2: pointwise 2x2 nuclear norm* ------------------------------------------------------
-            const double d0 = fwd_diff(ux, uxi, uxi, last_i, linear, P.inv_h1);
-            const double d1 = fwd_diff(ux, uxj, uxj, last_j, linear, P.inv_h2);
-            const double d2 = fwd_diff(uy, uyi, uyi, last_i, linear, P.inv_h1);
-            const double d3 = fwd_diff(uy, uyj, uyj, last_j, linear, P.inv_h2);
-            const double e0 = fwd_diff(uxb, uxbi, uxbi, last_i, linear, P.inv_h1);
-            const double e1 = fwd_diff(uxb, uxbj, uxbj, last_j, linear, P.inv_h2);
-            const double e2 = fwd_diff(uyb, uybi, uybi, last_i, linear, P.inv_h1);
-            const double e3 = fwd_diff(uyb, uybj, uybj, last_j, linear, P.inv_h2);
-            const double t0 = v0 + sigma * e0, t1 = v1 + sigma * e1, t2 = v2 + sigma * e2, t3 = v3 + sigma * e3;
-            double n0, n1, n2, n3, s1v;
-            if (N21) {
-                sums[DS_F2] += vmask * sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);           // NNE/norm21.m:52-56
-                const double nn = fmax(sqrt(t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3), P.mu2);   // :70
-                n0 = (P.mu2 * t0) / nn; n1 = (P.mu2 * t1) / nn; n2 = (P.mu2 * t2) / nn; n3 = (P.mu2 * t3) / nn;   // :71
-                n0 = rnd<S>(n0); n1 = rnd<S>(n1); n2 = rnd<S>(n2); n3 = rnd<S>(n3);
-                s1v = sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);                            // :65,81
-            } else {
-                sums[DS_F2] += vmask * nuc_2x2(d0, d1, d2, d3);                // NNE/pointwise_2x2_nn.m:32
-                proj_spectral_2x2(t0, t1, t2, t3, P.mu2, n0, n1, n2, n3, s1v); // :46-48 (Moreau), :56
+                const double d0 = fwd_diff(ux, uxi, uxi, last_i, linear, P.inv_h1);
+                const double d1 = fwd_diff(ux, uxj, uxj, last_j, linear, P.inv_h2);
+                const double d2 = fwd_diff(uy, uyi, uyi, last_i, linear, P.inv_h1);
+                const double d3 = fwd_diff(uy, uyj, uyj, last_j, linear, P.inv_h2);
+                const double e0 = fwd_diff(uxb, uxbi, uxbi, last_i, linear, P.inv_h1);
+                const double e1 = fwd_diff(uxb, uxbj, uxbj, last_j, linear, P.inv_h2);
+                const double e2 = fwd_diff(uyb, uybi, uybi, last_i, linear, P.inv_h1);
+                const double e3 = fwd_diff(uyb, uybj, uybj, last_j, linear, P.inv_h2);
+                const double t0 = v0 + sigma * e0, t1 = v1 + sigma * e1, t2 = v2 + sigma * e2, t3 = v3 + sigma * e3;
+                double n0, n1, n2, n3, s1v;
+                if (N21) {
+                    sums[DS_F2] += vmask * sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+                    const double nn = fmax(sqrt(t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3), P.mu2);
+                    n0 = (P.mu2 * t0) / nn; n1 = (P.mu2 * t1) / nn; n2 = (P.mu2 * t2) / nn; n3 = (P.mu2 * t3) / nn;
+                    n0 = rnd<S>(n0); n1 = rnd<S>(n1); n2 = rnd<S>(n2); n3 = rnd<S>(n3);
+                    s1v = sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+                } else {
+                    sums[DS_F2] += vmask * nuc_2x2(d0, d1, d2, d3);
+                    proj_spectral_2x2(t0, t1, t2, t3, P.mu2, n0, n1, n2, n3, s1v);
+                }
+                if (sizeof(S) == 4) { n0 = rnd<S>(n0); n1 = rnd<S>(n1); n2 = rnd<S>(n2); n3 = rnd<S>(n3); }
+                if (valid) {
+                    S *o1 = pout + (size_t)k * fs, *o2 = pout + ((size_t)K + 4 * (size_t)k) * fs;
+                    sto(o1, off, y1n);
+                    sto(o2, off, n0); sto(o2 + fs, off, n1); sto(o2 + 2 * fs, off, n2); sto(o2 + 3 * fs, off, n3);
+                    maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], fabs(y1n));
+                    maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], s1v);
+                }
+                sums[DS_UX] += vmask * ux;
+                sums[DS_UY] += vmask * uy;
             }
-            if (sizeof(S) == 4) { n0 = rnd<S>(n0); n1 = rnd<S>(n1); n2 = rnd<S>(n2); n3 = rnd<S>(n3); }
-            if (valid) {
-                S *o1 = pout + (size_t)k * fs, *o2 = pout + ((size_t)K + 4 * (size_t)k) * fs;
-                sto(o1, off, y1n);
-                sto(o2, off, n0); sto(o2 + fs, off, n1); sto(o2 + 2 * fs, off, n2); sto(o2 + 3 * fs, off, n3);
-                maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], fabs(y1n));
-                maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], s1v);
-            }
-            sums[DS_UX] += vmask * ux;
-            sums[DS_UY] += vmask * uy;
+            wave_lds_sync();   // hand-over and tiles of this step are complete before the next step touches them
         }
     }
-    // partial row of this workgroup: every wave stages its 20 scalars and both Gram accumulators in its OWN tile region
-    // (no barrier needed before), one barrier, fixed-order sum over the waves (same order as block_reduce_store /
-    // gram_block_store, which took six barriers)
     double *out = part + (size_t)blockIdx.x * CP_PSTRIDE;
     {
-        constexpr int WS = 2 * 16 * CP_TS;   // doubles per wave in tiles[]
+        constexpr int WS = 2 * 16 * CP_TS;
         static_assert(WS >= CP_PSTRIDE, "tile region too small for the staged partial row");
         double *st = tiles + wave * WS;
+        wave_lds_sync();
 #pragma unroll
         for (int a = 0; a < CP_NSUM; ++a) {
             const double v = wave_sum(sums[a]);
@@ -300,7 +335,7 @@ __global__ __launch_bounds__(NT, (NT == 256) ? 2 : 1) void k_mf_fused_tv(MfParam
             st[CP_NSCAL + 256 + e] = acc2[r];
         }
         __syncthreads();
-        for (int e = tid; e < CP_PSTRIDE; e += NT) {
+        for (int e = tid; e < CP_PSTRIDE; e += NWV * 64) {
             const bool is_max = (e >= CP_NSUM && e < CP_NSCAL);
             double v = tiles[e];
 #pragma unroll

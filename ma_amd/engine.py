@@ -81,13 +81,14 @@ def _load():
         "cp_mg_halo_unpack": [vp, C.c_int, C.c_int, C.c_int, vp],
         "cp_mg_state_pack": [vp, C.c_int, C.c_int, vp, vp],
         "cp_mg_state_unpack": [vp, C.c_int, C.c_int, vp, vp],
-        "cp_mg_begin": [vp, C.c_double, C.c_double, C.c_double],
+        "cp_mg_begin": [vp, C.c_double, C.c_double, C.c_double, C.c_int32],
         "cp_mg_stage": [vp, C.c_int, C.c_int32, vp, C.c_int32, C.c_double, C.c_int32, C.c_double],
         "cp_mg_end": [vp, C.c_int32],
         "cp_mg_stop_state": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
         "cp_mg_gram": [vp, C.c_int, dp, dp],
         "cp_mg_power_start": [vp, dp],
         "cp_singular_values_static": [C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp],
+        "cp_stream_copy_gbps": [C.c_int32, C.c_int64, C.c_int32, C.c_int32, dp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -123,7 +124,7 @@ EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_im
             "cp_downsample", "cp_iterate", "cp_iterate_begin", "cp_iterate_steps", "cp_iterate_end", "cp_sync",
             "cp_kernel_time_ms", "cp_set_stream", "cp_mg_partial_len",
             "cp_mg_halo_len", "cp_mg_halo_pack", "cp_mg_halo_unpack", "cp_mg_state_pack", "cp_mg_state_unpack", "cp_mg_begin", "cp_mg_stage", "cp_mg_end",
-            "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start", "cp_singular_values_static"]
+            "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start", "cp_singular_values_static", "cp_stream_copy_gbps"]
 
 BUF_X0, BUF_X1, BUF_P0, BUF_P1, BUF_XTMP = 0, 1, 2, 3, 4
 SEL_ALL, SEL_X_U, SEL_P_Y12, SEL_P_DY, SEL_P_Y2 = 0, 1, 2, 3, 4
@@ -323,8 +324,8 @@ class Engine:
     def state_unpack(self, xbuf, pbuf, from_right_ptr, from_left_ptr):
         _chk(lib.cp_mg_state_unpack(self._h, xbuf, pbuf, C.c_void_p(from_right_ptr or None), C.c_void_p(from_left_ptr or None)))
 
-    def mg_begin(self, theta, tau, sigma):
-        _chk(lib.cp_mg_begin(self._h, theta, tau, sigma))
+    def mg_begin(self, theta, tau, sigma, max_iters=4094):
+        _chk(lib.cp_mg_begin(self._h, theta, tau, sigma, int(max_iters)))
 
     def mg_stage(self, stage, n, dev_ptr, world=1, scale=1.0, check_stop=0, tol=0.0):
         _chk(lib.cp_mg_stage(self._h, stage, n, C.c_void_p(dev_ptr), world, scale, check_stop, tol))
@@ -375,3 +376,10 @@ def singular_values_static(device, field_ptr, m, n, k, sv_ptr, stream_ptr=0):
     """cp_singular_values_static: device pointers as plain ints (e.g. torch.Tensor.data_ptr()); asynchronous on the stream"""
     _chk(lib.cp_singular_values_static(int(device), C.c_void_p(field_ptr), int(m), int(n), int(k), C.c_void_p(sv_ptr),
                                        C.c_void_p(stream_ptr or None)))
+
+
+def stream_copy_gbps(device=0, nbytes=1 << 31, lane_bytes=16, repeats=3):
+    """cp_stream_copy_gbps: measured device-to-device copy rate (GB/s, read + write) of the library's own streaming kernel"""
+    out = C.c_double()
+    _chk(lib.cp_stream_copy_gbps(int(device), int(nbytes), int(lane_bytes), int(repeats), C.byref(out)))
+    return out.value

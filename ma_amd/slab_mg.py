@@ -277,7 +277,7 @@ class MultiGpuEngine:
         eng, w = self.eng, self.part.world
         self.exchange_x(E.BUF_X0)
         self.exchange_p(E.BUF_P0)
-        eng.mg_begin(theta, tau, sigma)       # x_old = x0 (halo columns included)
+        eng.mg_begin(theta, tau, sigma, max_iters)       # x_old = x0 (halo columns included); history rows 0..max_iters
         if self.fused:
             eng.mg_stage(E.STAGE_DUAL0, 0, self.red.data_ptr())
             self.comm.all_gather(self.gathered, self.red)
@@ -327,7 +327,7 @@ class MultiGpuEngine:
 
     def iterate(self, theta, tau, sigma, iters, check_stop=0, tol=0.0):
         """`iters` CP iterations from the canonical state (benchmark hook; the stop rule is off by default)"""
-        self.iterate_begin(theta, tau, sigma)
+        self.iterate_begin(theta, tau, sigma, iters)
         self.iterate_steps(iters, check_stop, tol)
         self.iterate_end()
 
