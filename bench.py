@@ -22,9 +22,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic elements per pixel-image per CP iteration, SURVEY.md section 8(d)
 ELEMS_ITER = {"tv": 37, "curvature": 31}
-# dominant kernel: NN-TV runs one fused kernel per iteration (k_mf_fused_tv: the whole iteration's 37 elements);
-# NN-curvature runs separate passes, the dual pass (reads x(3)+x_old(3)+p(4)+grad(2)+b(1), writes p(4)) dominates
-ELEMS_DOM = {"tv": 37, "curvature": 17}
+# dominant kernel: NN-TV runs one fused kernel per iteration (k_mf_fused_tv: the whole iteration's 37 elements).
+# NN-curvature runs two field passes: k_mf_fused_curv (primal step, y1, y3, both Gram matrices, the SVT: 31 - 8 = 23 of the
+# survey's elements) dominates; k_curv_y2 does the y2 update the survey charges 8 elements for (reads x(2) x_old(2) y2(2),
+# writes y2(2)). With CP_TUNE_CURV_SPLIT=1 (the split passes of round 1) the dual pass (17) dominates.
+CURV_SPLIT = os.environ.get("CP_TUNE_CURV_SPLIT", "0") not in ("", "0")
+ELEMS_DOM = {"tv": 37, "curvature": 17 if CURV_SPLIT else 23}
 
 
 def dominant_kernel(reg, k, bc, fp32):
@@ -34,7 +37,10 @@ def dominant_kernel(reg, k, bc, fp32):
         lin = "true" if bc == "linear" else "false"
         ka = 16 if k > 12 else (12 if k > 8 else (8 if k > 4 else 4))
         return f"k_mf_fused_tv<{S}, {lin}, {'true' if k == 16 else 'false'}, {ka}, false>"
-    return f"k_mf_dual<{S}, 0, 1>"
+    if CURV_SPLIT:
+        return f"k_mf_dual<{S}, 0, 1>"
+    ka = 16 if k > 12 else (12 if k > 8 else (8 if k > 4 else 4))
+    return f"k_mf_fused_curv<{S}, {'true' if bc == 'neumann' else 'false'}, {'true' if k == 16 else 'false'}, {ka}>"
 
 
 def measured_copy_gbs(dev_index):

@@ -10,6 +10,7 @@
 
 #include "../../include/cpengine.h"
 #include "cp_mfnn_fused.cuh"
+#include "cp_mfnn_curv.cuh"
 #include "cp_var.cuh"
 #include "cp_pair.cuh"
 
@@ -82,7 +83,9 @@ struct cp_engine {
                              // events costs a few microseconds of stream time; by default only the dominant kernel is timed)
     bool pw_split = false;   // tuning aid (CP_TUNE_PW_SPLIT=1): pairwise models on the split passes instead of k_pw_fused
     int fused_ka = 1;    // use the K <= 4 / 8 / 12 instantiations of k_mf_fused_tv (CP_TUNE_FUSED_KA=0: always 16)
-    int nblk_fused = 0;  // grid of k_mf_fused_tv (2 workgroups per CU resident: two LDS tiles per wave)
+    int nblk_fused = 0;  // grid of k_mf_fused_tv / k_mf_fused_curv (2 workgroups per CU resident: two LDS tiles per wave)
+    int nblk_y2 = 0;     // grid of k_curv_y2
+    bool curv_fused = false;   // NN-curvature on k_mf_fused_curv + k_curv_y2 (CP_TUNE_CURV_SPLIT=1: the split passes)
     bool linearized = false, has_nu = false, has_images = false;
     hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless cp_set_stream)
     int it_n = -1;                     // >= 0 between cp_iterate_begin / cp_mg_begin and the matching end: iterations done
@@ -338,6 +341,9 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         // resident: 2 per CU), tasks strided by the grid; a multiple of 8 workgroups keeps a part on one XCD. Measured at
         // 4096^2 x 16: 10.4-10.7 ms for grids of 4096, 2048, 1024; 10.8 ms for 512 (persistent).
         h->nblk_fused = (int)std::min<long long>((fused2_tasks(h->m, h->nl) + 7) / 8 * 8, CP_FUSED_MAXGRID);
+        h->curv_fused = mf && !var && h->reg == 1;
+        if (const char *ev = getenv("CP_TUNE_CURV_SPLIT")) { if (atoi(ev) != 0) h->curv_fused = false; }
+        if (mf) h->nblk_y2 = (int)std::min<long long>((curv_y2_tasks(h->m, h->nl, h->K) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         if (const char *ev = getenv("CP_TUNE_FUSED_KA")) h->fused_ka = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_PW_SPLIT")) h->pw_split = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_TIME_ALL")) h->time_all = atoi(ev) != 0;
@@ -345,7 +351,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
             HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
-            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(h->nblk, h->nblk_fused) * CP_PSTRIDE));
+            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(std::max(h->nblk, h->nblk_fused), h->nblk_y2) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->part2, sizeof(double) * (size_t)(CP_FUSED_MAXGRID / CP_S1_GROUP) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->svout, sizeof(double) * (16 + 256 + 256)));
             HIPCHK(hipMalloc(&h->red, sizeof(double) * CP_PSTRIDE));
@@ -795,10 +801,10 @@ __global__ __launch_bounds__(1024) void k_mf_reduce_stage1(int nrows, const doub
 
 // partial rows of the last field kernel as the single-workgroup kernels read them (after stage 1 if there are more than
 // 128: a single workgroup reads about 18 rows per microsecond)
-static const double *staged_partials(cp_engine *h, int nrows, int *rows) {
+static const double *staged_partials(cp_engine *h, int nrows, int *rows, bool scalars_only = false) {
     if (nrows <= 128) { *rows = nrows; return h->part; }
     const int r2 = (nrows + CP_S1_GROUP - 1) / CP_S1_GROUP;
-    hipLaunchKernelGGL(k_mf_reduce_stage1, dim3(r2, (CP_PSTRIDE + 255) / 256), dim3(1024), 0, h->stream, nrows, h->part,
+    hipLaunchKernelGGL(k_mf_reduce_stage1, dim3(r2, scalars_only ? 1 : (CP_PSTRIDE + 255) / 256), dim3(1024), 0, h->stream, nrows, h->part,
                        h->part2);
     *rows = r2;
     return h->part2;
@@ -852,6 +858,26 @@ static void launch_fused(cp_engine *h, const MfParams &P, const double *xp, doub
     else launch_fused_t<double>(h, P, xp, xc, pc, pn, W);
 }
 
+// NN-curvature: k_mf_fused_curv (x_{n-1} in xp, x_n -> xc; y_n in pc; y1_{n+1}, y3~_{n+1} -> pn) and k_curv_y2 (y2_{n+1} -> pn)
+template <typename S>
+static void launch_curv_t(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
+                          const double *W) {
+    const bool neu = (h->d.bc == CP_BC_NEUMANN);
+    auto kern = neu ? k_mf_fused_curv<S, true, false> : k_mf_fused_curv<S, false, false>;
+    if (h->K == CP_KMAX) kern = neu ? k_mf_fused_curv<S, true, true> : k_mf_fused_curv<S, false, true>;
+    else if (h->K <= 4 && h->fused_ka) kern = neu ? k_mf_fused_curv<S, true, false, 4> : k_mf_fused_curv<S, false, false, 4>;
+    else if (h->K <= 8 && h->fused_ka) kern = neu ? k_mf_fused_curv<S, true, false, 8> : k_mf_fused_curv<S, false, false, 8>;
+    else if (h->K <= 12 && h->fused_ka) kern = neu ? k_mf_fused_curv<S, true, false, 12> : k_mf_fused_curv<S, false, false, 12>;
+    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
+                       (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
+}
+template <typename S>
+static void launch_curv_y2_t(cp_engine *h, const MfParams &P, const double *xc, const double *xp, const double *pc, double *pn) {
+    auto kern = (h->d.bc == CP_BC_NEUMANN) ? k_curv_y2<S, true> : k_curv_y2<S, false>;
+    hipLaunchKernelGGL(kern, dim3(h->nblk_y2), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xc, (const S *)xp, (const S *)pc, (S *)pn,
+                       (const CpCtrl *)h->ctrl, h->part);
+}
+
 // ---- fused NN-TV path: F_0 = dual step 1 alone, then one k_mf_fused_tv + k_mf_efused per iteration -------------
 static int mf_fused_start(cp_engine *h, const MfParams &P, double tol) {
     CpCtrl *ctrl = (CpCtrl *)h->ctrl;
@@ -866,17 +892,31 @@ static int mf_fused_iterations(cp_engine *h, const MfParams &P, int n0, int coun
     for (int n = n0 + 1; n <= n0 + count; ++n) {
         const int cur = n & 1, prv = (n - 1) & 1, nxt = (n + 1) & 1;   // x_{n-1} in X[prv], y_n in P[cur]
         CPCHK(timer_begin(h, T_DUAL));
-        launch_fused(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[nxt], h->W[cur]);
+        if (h->reg == 0) launch_fused(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[nxt], h->W[cur]);
+        else if (h->fp32) launch_curv_t<float>(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[nxt], h->W[cur]);
+        else launch_curv_t<double>(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[nxt], h->W[cur]);
         CPCHK(timer_end(h, T_DUAL));
         EFusedArgs A;
         A.K = h->K; A.n = n; A.check_stop = check; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
-        A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot; A.norm21 = P.norm21;
+        A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot; A.norm21 = P.norm21; A.reg = h->reg;
         A.warm = efused_warm(n);
         if (h->time_all) CPCHK(timer_begin(h, T_EIG));
         const double *rows = fused_partials(h, &A.nblk);
         hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, rows, ctrl, h->W[nxt], h->hist_p,
                            h->hist_d, h->vwarm);
         if (h->time_all) CPCHK(timer_end(h, T_EIG));
+        if (h->reg != 0) {   // NN-curvature: y2_{n+1}, then F2 / F2* / the boundary term of the next mean / the stop rule
+            CPCHK(timer_begin(h, T_PRIMAL));
+            if (h->fp32) launch_curv_y2_t<float>(h, P, h->X[cur], h->X[prv], h->P[cur], h->P[nxt]);
+            else launch_curv_y2_t<double>(h, P, h->X[cur], h->X[prv], h->P[cur], h->P[nxt]);
+            CPCHK(timer_end(h, T_PRIMAL));
+            CurvFinArgs F;
+            F.n = n; F.check_stop = check; F.tol = tol; F.mu2 = P.mu2; F.tau = P.tau; F.Ntot = P.Ntot;
+            if (h->time_all) CPCHK(timer_begin(h, T_FIN));
+            const double *rows2 = staged_partials(h, h->nblk_y2, &F.nblk, true);
+            hipLaunchKernelGGL(k_curv_fin, dim3(1), dim3(256), 0, h->stream, F, rows2, ctrl, h->hist_p, h->hist_d);
+            if (h->time_all) CPCHK(timer_end(h, T_FIN));
+        }
     }
     HIPCHK(hipGetLastError());
     return CP_OK;
@@ -1034,7 +1074,7 @@ static int solve_mf(cp_engine *h, double theta, double tau, double sigma, int ma
     HIPCHK(hipGetLastError());
     int done = 0, stopped = 0, stop_iter = -1;
     const int chunk = 32;
-    const bool fused = (h->reg == 0);
+    const bool fused = (h->reg == 0) || h->curv_fused;
     if (fused && maxIter > 0) CPCHK(mf_fused_start(h, P, tol));
     while (done < maxIter && !stopped) {
         const int cnt = std::min(chunk, maxIter - done);
@@ -1390,7 +1430,7 @@ extern "C" int cp_iterate_begin(cp_handle h, double theta, double tau, double si
     if (h->mf) {
         const MfParams P = mf_params(h, theta, tau, sigma);
         CPCHK(mf_begin(h));
-        if (h->reg == 0 && !h->var) CPCHK(mf_fused_start(h, P, 0.0));
+        if ((h->reg == 0 || h->curv_fused) && !h->var) CPCHK(mf_fused_start(h, P, 0.0));
     } else {
         HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(PwCtrl) * h->batch, h->stream));
         HIPCHK(hipMemcpyAsync(h->X[1], h->X[0], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));
@@ -1413,7 +1453,7 @@ extern "C" int cp_iterate_steps(cp_handle h, int32_t iters) {
     if (h->mf) {
         const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
         if (h->var) CPCHK(var_iterations(h, P, h->it_n, iters, 0, 0.0));
-        else if (h->reg == 0) CPCHK(mf_fused_iterations(h, P, h->it_n, iters, 0, 0.0));
+        else if (h->reg == 0 || h->curv_fused) CPCHK(mf_fused_iterations(h, P, h->it_n, iters, 0, 0.0));
         else CPCHK(mf_iterations(h, P, h->it_n, iters, 0, 0.0));
     } else {
         const PwParams P = pw_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
@@ -1677,7 +1717,7 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
         case CP_STAGE_EFUSED: {
             EFusedArgs A;
             A.nblk = world; A.K = h->K; A.n = n; A.check_stop = check_stop; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
-            A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot; A.norm21 = P.norm21;
+            A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot; A.norm21 = P.norm21; A.reg = 0;
             A.warm = efused_warm(n);
             if (h->time_all) CPCHK(timer_begin(h, T_EIG));
             hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->W[(n + 1) & 1],

@@ -48,6 +48,7 @@ struct MfParams {
 // slots of the per-block partial buffer
 enum { DS_F1 = 0, DS_F2, DS_F1S, DS_UX, DS_UY, DS_F2S, DS_SGX, DS_SGY,   // dual-side sums
        PS_WX, PS_UX, PS_UY };                                             // primal-side sums
+enum { DS_BSX = PS_UX, DS_BSY = PS_UY };   // dual-side kernels of the curvature model: sum of y2_new * rowsum(Lap) per component
 enum { DM_Y1 = CP_NSUM, DM_S1,                                            // dual-side maxima
        PM_WXMAX, PM_WXMIN, PM_WYMAX, PM_WYMIN, PM_VL };                   // primal-side maxima
 
@@ -262,6 +263,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const S *__res
                     }
                     const double z0 = n0 / P.mu2, z1 = n1 / P.mu2;
                     sums[DS_F2S] += z0 * z0 + z1 * z1;                           // NNE/SSD.m:66-67
+                    if (!neumann) {   // sum of Lap(y2) = sum of y2 * rowsum(Lap): the mean of the next u (fused curvature passes)
+                        const double rs = -((first_i ? 1.0 : 0.0) + (last_i ? 1.0 : 0.0)) * ih1 - ((first_j ? 1.0 : 0.0) + (last_j ? 1.0 : 0.0)) * ih2;
+                        sums[DS_BSX] += n0 * rs;
+                        sums[DS_BSY] += n1 * rs;
+                    }
                 }
                 sums[DS_UX] += ux;
                 sums[DS_UY] += uy;

@@ -1,0 +1,343 @@
+// NN-curvature (NNE/mf_nn_curvature_registration_no_ref_ml.m) in two field passes per Chambolle-Pock iteration.
+//
+// The 5-point Laplacian sits on both sides of the iteration (A2 = discrete_laplacian, symmetric), so the one-kernel
+// recomputation of k_mf_fused_tv would need the primal step at 5 positions and y2 at 13. The iteration is split where
+// the stencils are instead:
+//   k_mf_fused_curv(n)  primal step n -- u_n from the Laplacian of y2_n (read-only here), L_n -- and everything of dual
+//                       step n+1 that is pointwise in xbar_n: y1_{n+1} (SAD*), y3~_{n+1} with both Gram matrices.
+//                       reads u(2) L y1 y2(2) y3 gradT(2) b, writes u(2) L y1 y3 = 15 elements per pixel-image
+//   k_mf_efused(n)      reduction, eigensolves, W_{n+1}, history rows (cp_mfnn_fused.cuh, reg = 1)
+//   k_curv_y2(n)        y2_{n+1} = prox_{sigma F2*}(y2_n + sigma*Lap(ubar_n)), F2(A x_n), F2*(y2_{n+1}).
+//                       reads u_n(2) u_{n-1}(2) y2(2), writes y2(2) = 8 elements
+//   k_curv_fin(n)       F2 / F2* into the history rows, mean of the next un-projected u, stop rule
+// 23 elements instead of the 29 of the split passes (k_mf_dual + k_mf_primal), and no position is recomputed.
+// The mean of the next u follows as in k_mf_fused_tv with one more term: mean(Lap y2) is not zero under Dirichlet rows,
+// but equals sum_q y2(q) * rowsum_q(Lap) / N (the Laplacian is symmetric), accumulated over the boundary pixels while
+// y2_{n+1} is written.
+#pragma once
+#include "cp_mfnn_fused.cuh"
+#include "cp_var.cuh"   // reduce_scalars
+
+
+// row sum of the 5-point Laplacian at pixel (i, jg): 0 in the interior and for neumann rows
+// (NNE/discrete_laplacian.m:25-27: diagonal -1/h^2 at the ends), -1/h^2 per missing neighbour for dirichlet rows (:28)
+__device__ __forceinline__ double lap_rowsum(bool neumann, bool first_i, bool last_i, bool first_j, bool last_j, double ih1,
+                                             double ih2) {
+    if (neumann) return 0.0;
+    return -((first_i ? 1.0 : 0.0) + (last_i ? 1.0 : 0.0)) * ih1 - ((first_j ? 1.0 : 0.0) + (last_j ? 1.0 : 0.0)) * ih2;
+}
+
+// Same organisation as k_mf_fused_tv: a wave marches down one image column in segments of 64 rows, four adjacent
+// columns per workgroup, no workgroup barrier in the loop. y2_n at (i+1, j) is lane+1's own value (lane 63: the value
+// lane 0 loaded one step earlier, through LDS; at the top of a part a load in lane 63 alone), at (i-1, j) one
+// element-shifted load, at (i, j-1) and (i, j+1) the lines the neighbouring waves stream.
+template <typename S, bool NEUMANN, bool FULLK, int KA = CP_KMAX>
+__global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_curv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
+                                                                const S *__restrict__ pin, S *__restrict__ pout,
+                                                                const S *__restrict__ g, const S *__restrict__ b,
+                                                                const double *__restrict__ W,
+                                                                const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
+    constexpr int NWV = CP_WAVES;
+    __shared__ double tiles[NWV * 2 * 16 * CP_TS];
+    __shared__ double Wl[CP_KMAX * CP_KMAX];
+    __shared__ double carry_all[NWV * 2 * CP_KMAX * 2];   // [wave][step parity][image][y2 component] of lane 0
+    const int stopped = ctrl->stop;
+    const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *tileA = tiles + wave * 2 * 16 * CP_TS, *tileB = tileA + 16 * CP_TS;
+    double *carry = carry_all + wave * 2 * CP_KMAX * 2;
+    const int K = P.K, m = P.m;
+    const size_t fs = (size_t)P.fs;
+    stage_W(W, Wl);
+    if (stopped) return;
+    if (KA < CP_KMAX) {
+        for (int k = KA; k < CP_KMAX; ++k) tileA[k * CP_TS + lane] = 0.0;
+    }
+    __syncthreads();
+    const double sigma = P.sigma, tau = P.tau, theta = P.theta, inv_sigma = 1.0 / P.sigma;
+    const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
+    const S *y3in = pin + 3 * (size_t)K * fs;
+    S *y3out = pout + 3 * (size_t)K * fs;
+    const S *Lin = xo + 2 * (size_t)K * fs;
+    S *Lout = xn + 2 * (size_t)K * fs;
+    constexpr unsigned ES = (unsigned)sizeof(S);
+    const unsigned mb = ES * (unsigned)m;
+
+    double sums[CP_NSUM], maxs[CP_NMAX];
+#pragma unroll
+    for (int a = 0; a < CP_NSUM; ++a) sums[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < CP_NMAX; ++a) maxs[a] = -1.0e300;
+    maxs[DM_Y1 - CP_NSUM] = 0.0; maxs[DM_S1 - CP_NSUM] = 0.0; maxs[PM_VL - CP_NSUM] = 0.0;
+    double4_t acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+
+    const Fused2Geom GM = fused2_geom(m);
+    const int ntasks = GM.parts * ((P.nl + NWV - 1) / NWV);
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const int cg = task / GM.parts, pt = task - cg * GM.parts;
+        const int j = cg * NWV + wave;
+        if (j >= P.nl) continue;                                   // wave-uniform
+        const int seg_lo = pt * GM.steps, seg_hi = min(seg_lo + GM.steps, GM.nseg) - 1;
+        const int jg = P.j_off + j;
+        const bool first_j = (jg == 0), last_j = (jg == P.n_global - 1);
+        for (int sg = seg_hi; sg >= seg_lo; --sg) {
+            const int par = (seg_hi - sg) & 1;
+            const int ii = sg * 64 + lane;
+            const bool valid = ii < m;
+            const int i = min(ii, m - 1);
+            const unsigned off = ES * (unsigned)((j + 1) * m + i);
+            const bool first_i = (i == 0), last_i = (i == m - 1);
+
+            fused_phase1<S, FULLK, KA>(P, K, valid, off, lane, fs, y3in, pin, Lin, y3out, Lout, Wl, tileA, tileB, sigma, tau,
+                                       theta, maxs[PM_VL - CP_NSUM], acc1, acc2);
+
+            // ---- per image: primal step of u at the own pixel (Laplacian of y2_n), y1_{n+1} ---------------------------------
+            const bool want = valid && !last_i;                    // y2_n at (i+1, j) is used
+            const bool from_carry = want && lane == 63 && sg < seg_hi;
+            const bool reload = want && lane == 63 && sg == seg_hi;
+            const bool any_reload = __any(reload);                 // wave-uniform: first step of a part below the image's top
+            const double *cin = carry + (par ^ 1) * CP_KMAX * 2;
+            double *cout_ = carry + par * CP_KMAX * 2;
+            const double vmask = valid ? 1.0 : 0.0;
+            for (int k = 0; k < K; ++k) {
+                const S *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 2 * (size_t)k) * fs;
+                const S *gxk = g + 2 * (size_t)k * fs, *uxk = xo + 2 * (size_t)k * fs;
+                const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
+                const double y1 = ldo(y1k, off);
+                const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
+                const double bb = ldo_stream(b + (size_t)k * fs, off);
+                const double uxo_ = ldo_stream(uxk, off), uyo_ = ldo_stream(uxk + fs, off);
+                double lap[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const S *f = y2k + (size_t)c * fs;
+                    const double w0 = ldo(f, off);
+                    const double wim = ldo(f, off, -(int)ES);
+                    const double wjm = ldo(f, off - mb), wjp = ldo(f, off + mb);
+                    double wip = __shfl(w0, lane + 1);
+                    if (from_carry) wip = cin[2 * k + c];
+                    if (any_reload) {
+                        if (reload) wip = ldo(f, off, (int)ES);
+                    }
+                    if (lane == 0) cout_[2 * k + c] = w0;
+                    // NNE/discrete_laplacian.m:23-46: a missing neighbour is the centre value (neumann) or zero (dirichlet)
+                    const double a0 = !first_i ? wim : (NEUMANN ? w0 : 0.0);
+                    const double a1 = !last_i ? wip : (NEUMANN ? w0 : 0.0);
+                    const double a2 = !first_j ? wjm : (NEUMANN ? w0 : 0.0);
+                    const double a3 = !last_j ? wjp : (NEUMANN ? w0 : 0.0);
+                    lap[c] = (a0 + a1 - 2.0 * w0) * ih1 + (a2 + a3 - 2.0 * w0) * ih2;
+                }
+                const double vux = -gx * y1 + lap[0];              // (A'y)_u = -grad T' y1 + Lap y2
+                const double vuy = -gy * y1 + lap[1];
+                const double ux = rnd<S>((uxo_ - tau * vux) - cnx);    // NNE/mean_zero_indicator.m:50,53
+                const double uy = rnd<S>((uyo_ - tau * vuy) - cny);
+                const double wx = -vux, wy = -vuy;
+                S *uxo_k = xn + 2 * (size_t)k * fs;
+                if (valid) {
+                    sto(uxo_k, off, ux);
+                    sto(uxo_k + fs, off, uy);
+                    maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], wx);     // NNE/mean_zero_indicator.m:78-84
+                    maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], -wx);
+                    maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], wy);
+                    maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], -wy);
+                }
+                sums[PS_WX] += vmask * wx;
+                const double uxb = ux + theta * (ux - uxo_), uyb = uy + theta * (uy - uyo_);
+                // ---- y1: SAD* (identical to k_mf_dual) ----------------------------------------------------------------
+                const double r_cur = -(gx * ux + gy * uy) + Lc;
+                const double r_bar = -(gx * uxb + gy * uyb) + Lbar;
+                sums[DS_F1] += vmask * fabs(r_cur - bb);                              // NNE/SAD.m:54
+                const double yt = y1 + sigma * r_bar;
+                const double Ls = yt * inv_sigma, thr = inv_sigma * P.mu1, dd = Ls - bb;
+                const double prox = (dd > thr) ? (Ls - thr) : ((dd < -thr) ? (Ls + thr) : bb);   // :42-49
+                const double y1n = rnd<S>(yt - sigma * prox);                         // :71-72
+                sums[DS_F1S] += vmask * (y1n * bb);                                   // :83
+                sums[DS_SGX] += vmask * (gx * y1n);
+                sums[DS_SGY] += vmask * (gy * y1n);
+                if (valid) {
+                    sto(pout + (size_t)k * fs, off, y1n);
+                    maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], fabs(y1n));
+                }
+                sums[DS_UX] += vmask * ux;
+                sums[DS_UY] += vmask * uy;
+            }
+            wave_lds_sync();
+        }
+    }
+    double *out = part + (size_t)blockIdx.x * CP_PSTRIDE;
+    {
+        constexpr int WS = 2 * 16 * CP_TS;
+        double *st = tiles + wave * WS;
+        wave_lds_sync();
+#pragma unroll
+        for (int a = 0; a < CP_NSUM; ++a) {
+            const double v = wave_sum(sums[a]);
+            if (lane == 0) st[a] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < CP_NMAX; ++a) {
+            const double v = wave_max(maxs[a]);
+            if (lane == 0) st[CP_NSUM + a] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = ((lane >> 4) + 4 * r) * 16 + (lane & 15);
+            st[CP_NSCAL + e] = acc1[r];
+            st[CP_NSCAL + 256 + e] = acc2[r];
+        }
+        __syncthreads();
+        for (int e = tid; e < CP_PSTRIDE; e += CP_BLOCK) {
+            const bool is_max = (e >= CP_NSUM && e < CP_NSCAL);
+            double v = tiles[e];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) {
+                const double o = tiles[w * WS + e];
+                v = is_max ? fmax(v, o) : v + o;
+            }
+            out[e] = v;
+        }
+    }
+}
+
+// ---- k_curv_y2: y2_{n+1} = prox_{sigma F2*}(y2_n + sigma*Lap(ubar_n)), ubar_n = u_n + theta*(u_n - u_{n-1}) -----------------
+// The 2K fields do not couple here. A wave owns 64 rows and marches along j through a strip of columns, one field at a
+// time, with a three-column window of u_n and u_{n-1} in registers: every element is loaded once by its wave; (i +- 1, j)
+// are lane +- 1's window values (cross-lane shift), lanes 0 and 63 load the two rows outside the segment. The four waves of
+// a workgroup are four vertically adjacent segments (256 rows), so three of every four of those rows are lines the
+// neighbouring wave streams at the same moment. Tasks: (row block, column strip, field group).
+struct CurvY2Geom { int rblocks, strips, strips8, strip_w, fgroups, fields_per_group; };
+__host__ __device__ inline CurvY2Geom curv_y2_geom(int m, int nl, int K) {
+    CurvY2Geom G;
+    G.rblocks = (m + 255) / 256;
+    G.strip_w = nl < 32 ? nl : 32;
+    G.strips = (nl + G.strip_w - 1) / G.strip_w;
+    G.fgroups = 1;
+    while ((long long)G.rblocks * G.strips * G.fgroups < 2048 && G.fgroups < 2 * K) G.fgroups *= 2;
+    G.fields_per_group = (2 * K + G.fgroups - 1) / G.fgroups;
+    G.fgroups = (2 * K + G.fields_per_group - 1) / G.fields_per_group;
+    G.strips8 = (G.strips + 7) / 8;
+    return G;
+}
+// task ids: strip index mod 8 fastest (= the XCD, workgroups are dealt round robin), then the row block: vertically
+// adjacent row blocks of one strip are consecutive workgroups of one XCD and share the rows between them in its L2
+__host__ __device__ inline long long curv_y2_tasks(int m, int nl, int K) {
+    const CurvY2Geom G = curv_y2_geom(m, nl, K);
+    return 8LL * G.rblocks * G.strips8 * G.fgroups;
+}
+
+template <typename S, bool NEUMANN>
+__global__ __launch_bounds__(CP_BLOCK) void k_curv_y2(MfParams P, const S *__restrict__ xc, const S *__restrict__ xo,
+                                                      const S *__restrict__ pin, S *__restrict__ pout,
+                                                      const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
+    __shared__ double red[CP_WAVES * CP_NSCAL];
+    if (ctrl->stop) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = P.K, m = P.m;
+    const size_t fs = (size_t)P.fs;
+    const double sigma = P.sigma, theta = P.theta, inv_sigma = 1.0 / P.sigma;
+    const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
+    const double den = 1.0 + P.mu2 * inv_sigma;
+    constexpr unsigned ES = (unsigned)sizeof(S);
+    const unsigned mb = ES * (unsigned)m;
+    double sums[CP_NSUM], maxs[CP_NMAX];
+#pragma unroll
+    for (int a = 0; a < CP_NSUM; ++a) sums[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < CP_NMAX; ++a) maxs[a] = 0.0;
+
+    const CurvY2Geom GM = curv_y2_geom(m, P.nl, K);
+    const int ntasks = 8 * GM.rblocks * GM.strips8 * GM.fgroups;
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        int q = task >> 3;
+        const int rb = q % GM.rblocks;
+        q /= GM.rblocks;
+        const int cs = (q % GM.strips8) * 8 + (task & 7), fg = q / GM.strips8;
+        const int ii = rb * 256 + wave * 64 + lane;
+        if (cs >= GM.strips || rb * 256 + wave * 64 >= m) continue;   // wave-uniform
+        const bool valid = ii < m;
+        const int i = min(ii, m - 1);
+        const bool first_i = (i == 0), last_i = (i == m - 1);
+        const int j0 = cs * GM.strip_w, j1 = min(j0 + GM.strip_w, P.nl);
+        const int f0 = fg * GM.fields_per_group, f1 = min(f0 + GM.fields_per_group, 2 * K);
+        // lanes 0 and 63 fetch the rows just outside the segment (if they exist); a lane past the end of the image
+        // never needs one (its value is not used)
+        const bool edge_dn = (lane == 0) && !first_i, edge_up = (lane == 63) && valid && !last_i;
+        for (int f = f0; f < f1; ++f) {
+            const S *un = xc + (size_t)f * fs, *uo = xo + (size_t)f * fs;
+            const S *y2i = pin + ((size_t)K + f) * fs;
+            S *y2o = pout + ((size_t)K + f) * fs;
+            unsigned off = ES * (unsigned)((j0 + 1) * m + i);     // (i, j0)
+            double an_m = ldo(un, off - mb), ao_m = ldo(uo, off - mb);   // column j0 - 1 (halo column at the slab's edge)
+            double an_c = ldo_stream(un, off), ao_c = ldo_stream(uo, off);
+            for (int j = j0; j < j1; ++j, off += mb) {
+                const int jg = P.j_off + j;
+                const bool first_j = (jg == 0), last_j = (jg == P.n_global - 1);
+                // the last column of a strip is the first of the next one: a plain (cacheable) load there
+                const double an_p = (j + 1 < j1) ? ldo_stream(un, off + mb) : ldo(un, off + mb);
+                const double ao_p = (j + 1 < j1) ? ldo_stream(uo, off + mb) : ldo(uo, off + mb);
+                const double v = ldo_stream(y2i, off);
+                double an_u = __shfl(an_c, lane + 1), ao_u = __shfl(ao_c, lane + 1);   // (i+1, j)
+                double an_d = __shfl(an_c, lane - 1), ao_d = __shfl(ao_c, lane - 1);   // (i-1, j)
+                if (edge_up) { an_u = ldo(un, off, (int)ES); ao_u = ldo(uo, off, (int)ES); }
+                if (edge_dn) { an_d = ldo(un, off, -(int)ES); ao_d = ldo(uo, off, -(int)ES); }
+                // as k_mf_dual: xbar at the five points first, then the Laplacian (NNE/discrete_laplacian.m:23-46)
+                const double uc0 = an_c, ub0 = an_c + theta * (an_c - ao_c);
+                const bool have[4] = {!first_i, !last_i, !first_j, !last_j};
+                const double na[4] = {an_d, an_u, an_m, an_p}, no[4] = {ao_d, ao_u, ao_m, ao_p};
+                double nb[4], nbb[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    nb[d] = have[d] ? na[d] : (NEUMANN ? uc0 : 0.0);
+                    nbb[d] = have[d] ? na[d] + theta * (na[d] - no[d]) : (NEUMANN ? ub0 : 0.0);
+                }
+                const double lapc = (nb[0] + nb[1] - 2.0 * uc0) * ih1 + (nb[2] + nb[3] - 2.0 * uc0) * ih2;
+                const double lapb = (nbb[0] + nbb[1] - 2.0 * ub0) * ih1 + (nbb[2] + nbb[3] - 2.0 * ub0) * ih2;
+                const double t0 = v + sigma * lapb;
+                const double n0 = rnd<S>(t0 - sigma * ((t0 * inv_sigma) / den));      // NNE/SSD.m:60-61 with :43 (g = 0)
+                if (valid) {
+                    sto(y2o, off, n0);
+                    sums[DS_F2] += lapc * lapc;                                       // NNE/SSD.m:48 (g = 0)
+                    const double z0 = n0 / P.mu2;
+                    sums[DS_F2S] += z0 * z0;                                          // NNE/SSD.m:66-67
+                    const double rs = lap_rowsum(NEUMANN, first_i, last_i, first_j, last_j, ih1, ih2);
+                    if (f & 1) sums[DS_BSY] += n0 * rs; else sums[DS_BSX] += n0 * rs;
+                }
+                an_m = an_c; ao_m = ao_c; an_c = an_p; ao_c = ao_p;
+            }
+        }
+    }
+    block_reduce_store<CP_NSUM, CP_NMAX>(sums, maxs, red, part + (size_t)blockIdx.x * CP_PSTRIDE);
+}
+
+struct CurvFinArgs {
+    int nblk, n, check_stop;
+    double tol, mu2, tau, Ntot;
+};
+
+// after k_curv_y2(n): F2(A x_n) completes primal row n, F2*(y2_{n+1}) goes into dual row n+1, the boundary term of the
+// mean of the next un-projected u, and the stop rule for i = n (PDO/chambolle_pock.m:142-153; every entry of rows n-4..n
+// is final now: k_mf_efused(n) ran before on the same stream)
+__global__ __launch_bounds__(256) void k_curv_fin(CurvFinArgs A, const double *__restrict__ part, CpCtrl *ctrl,
+                                                  double *hist_p, double *hist_d) {
+    __shared__ double sc[CP_NSCAL], stage[256];
+    if (ctrl->stop) return;
+    reduce_scalars(part, A.nblk, sc, stage);
+    if (threadIdx.x != 0) return;
+    const int n = A.n;
+    double *hp = hist_p + (size_t)n * CP_HCOLS_MF, *hd1 = hist_d + (size_t)(n + 1) * CP_HCOLS_MF;
+    const double F2 = A.mu2 * 0.5 * sc[DS_F2];
+    hp[2] = F2;
+    hp[0] = hp[4] + (hp[1] + F2 + 0.0);                        // chambolle_pock.m:170-171
+    hd1[2] = A.mu2 * (0.5 * sc[DS_F2S]);                       // NNE/SSD.m:66-67 (g = 0)
+    ctrl->cn[0] -= A.tau * (sc[DS_BSX] / A.Ntot);              // - tau * mean(Lap y2_{n+1}), zero for neumann rows
+    ctrl->cn[1] -= A.tau * (sc[DS_BSY] / A.Ntot);
+    if (A.check_stop && n >= 4) {
+        bool ok = true;
+        for (int r = n - 4; r <= n; ++r) {
+            const double *p_ = hist_p + (size_t)r * CP_HCOLS_MF, *d_ = hist_d + (size_t)r * CP_HCOLS_MF;
+            const double gap = fabs((p_[0] - d_[0]) / d_[0]);
+            if (!(gap <= A.tol) || !(p_[5] <= A.tol) || !(p_[6] <= A.tol) || !(d_[5] <= A.tol) || !(d_[6] <= A.tol)) ok = false;
+        }
+        if (ok) { ctrl->stop = 1; ctrl->stop_iter = n; }
+    }
+}

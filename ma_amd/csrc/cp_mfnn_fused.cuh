@@ -70,6 +70,81 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
     wy = -vuy;
 }
 
+// Phase 1 of the fused passes (NN-TV and NN-curvature): everything that couples the K images of one pixel.
+//   y3_n = y3~_n * W_n (lazy nuclear-norm prox), (A'y)_L = y1_n + B*y3_n, L_n = L_{n-1} - tau*(A'y)_L (zero_function prox),
+//   Lbar = L_n + theta*(L_n - L_{n-1}), y3~_{n+1} = y3_n + sigma*B*Lbar; stores L_n and y3~_{n+1}; accumulates the Gram
+//   matrices of y3~_{n+1} (acc1) and of B*L_n (acc2) on the matrix cores; leaves L_n in tileA and Lbar in tileB (row =
+//   image, column = lane) for the per-image phase. The tiles are wave-private: only the order of the wave's own LDS
+//   instructions matters (wave_lds_sync), no workgroup barrier.
+template <typename S, bool FULLK, int KA>
+__device__ __forceinline__ void fused_phase1(const MfParams &P, int K, bool valid, unsigned off, int lane, size_t fs,
+                                             const S *__restrict__ y3in, const S *__restrict__ pin,
+                                             const S *__restrict__ Lin, S *__restrict__ y3out, S *__restrict__ Lout,
+                                             const double *Wl, double *tileA, double *tileB, double sigma, double tau,
+                                             double theta, double &vl_max, double4_t &acc1, double4_t &acc2) {
+    double a[KA], Lr[KA], y1v[KA];
+    {
+        double t3[KA];
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+            const int kk = (FULLK || k < K) ? k : K - 1;
+            t3[k] = ldo_stream(y3in + (size_t)kk * fs, off);
+            y1v[k] = ldo(pin + (size_t)kk * fs, off);
+            Lr[k] = ldo_stream(Lin + (size_t)kk * fs, off);
+        }
+#pragma unroll
+        for (int kp = 0; kp < KA; ++kp) a[kp] = 0.0;
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+            const double t = (FULLK || k < K) ? t3[k] : 0.0;
+#pragma unroll
+            for (int kp = 0; kp < KA; ++kp) a[kp] = fma(t, Wl[k * CP_KMAX + kp], a[kp]);
+        }
+    }
+    double s3 = 0.0;
+#pragma unroll
+    for (int kp = 0; kp < KA; ++kp) s3 += a[kp];
+    const double mean3 = s3 * P.invK;
+    double sumL = 0.0, sumLb = 0.0, vLmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+        const bool act = FULLK || (k < K);
+        const double Lo = Lr[k];
+        const double vL = y1v[k] + (a[k] - mean3);
+        const double Ln = rnd<S>(Lo - tau * vL);
+        const double Lb = Ln + theta * (Ln - Lo);
+        vLmax = fmax(vLmax, act ? fabs(vL) : 0.0);
+        Lr[k] = act ? Ln : 0.0;
+        a[k] = a[k] + sigma * Lb;
+        sumL += act ? Ln : 0.0;
+        sumLb += act ? Lb : 0.0;
+        tileB[k * CP_TS + lane] = Lb;
+    }
+    if (valid) vl_max = fmax(vl_max, vLmax);
+    const double smb = sigma * (sumLb * P.invK), mL = sumL * P.invK;
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+        const bool act = FULLK || (k < K);
+        const double v = (valid && act) ? rnd<S>(a[k] - smb) : 0.0;
+        tileA[k * CP_TS + lane] = v;
+        if (valid && act) {
+            sto(y3out + (size_t)k * fs, off, v);
+            sto(Lout + (size_t)k * fs, off, Lr[k]);
+        }
+    }
+    wave_lds_sync();
+    gram_tile_accum(tileA, acc1);
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < KA; ++k)
+        tileA[k * CP_TS + lane] = (valid && (FULLK || k < K)) ? Lr[k] - mL : 0.0;
+    wave_lds_sync();
+    gram_tile_accum(tileA, acc2);
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < KA; ++k) tileA[k * CP_TS + lane] = Lr[k];
+}
+
 // ---- k_mf_fused_tv: organised by wavefront -----------------------------------------------------------------------------
 // A wavefront owns one image column and marches DOWN it in aligned segments of 64 rows (a "part" of `steps` segments per
 // task), so that the (i+1, j) neighbour of every row is an own-pixel result that already exists: lane+1's in the same
@@ -154,68 +229,9 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S
             const unsigned off = ES * (unsigned)((j + 1) * m + i);
             const bool last_i = (i == m - 1);
 
-            // ---- phase 1: everything that couples the K images of this pixel (as in k_mf_fused_tv) ---------------------
-            double a[KA], Lr[KA], y1v[KA];
-            {
-                double t3[KA];
-#pragma unroll
-                for (int k = 0; k < KA; ++k) {
-                    const int kk = (FULLK || k < K) ? k : K - 1;
-                    t3[k] = ldo_stream(y3in + (size_t)kk * fs, off);
-                    y1v[k] = ldo(pin + (size_t)kk * fs, off);
-                    Lr[k] = ldo_stream(Lin + (size_t)kk * fs, off);
-                }
-#pragma unroll
-                for (int kp = 0; kp < KA; ++kp) a[kp] = 0.0;
-#pragma unroll
-                for (int k = 0; k < KA; ++k) {
-                    const double t = (FULLK || k < K) ? t3[k] : 0.0;
-#pragma unroll
-                    for (int kp = 0; kp < KA; ++kp) a[kp] = fma(t, Wl[k * CP_KMAX + kp], a[kp]);
-                }
-            }
-            double s3 = 0.0;
-#pragma unroll
-            for (int kp = 0; kp < KA; ++kp) s3 += a[kp];
-            const double mean3 = s3 * P.invK;
-            double sumL = 0.0, sumLb = 0.0, vLmax = 0.0;
-#pragma unroll
-            for (int k = 0; k < KA; ++k) {
-                const bool act = FULLK || (k < K);
-                const double Lo = Lr[k];
-                const double vL = y1v[k] + (a[k] - mean3);
-                const double Ln = rnd<S>(Lo - tau * vL);
-                const double Lb = Ln + theta * (Ln - Lo);
-                vLmax = fmax(vLmax, act ? fabs(vL) : 0.0);
-                Lr[k] = act ? Ln : 0.0;
-                a[k] = a[k] + sigma * Lb;
-                sumL += act ? Ln : 0.0;
-                sumLb += act ? Lb : 0.0;
-                tileB[k * CP_TS + lane] = Lb;
-            }
-            if (valid) maxs[PM_VL - CP_NSUM] = fmax(maxs[PM_VL - CP_NSUM], vLmax);
-            const double smb = sigma * (sumLb * P.invK), mL = sumL * P.invK;
-#pragma unroll
-            for (int k = 0; k < KA; ++k) {
-                const bool act = FULLK || (k < K);
-                const double v = (valid && act) ? rnd<S>(a[k] - smb) : 0.0;
-                tileA[k * CP_TS + lane] = v;
-                if (valid && act) {
-                    sto(y3out + (size_t)k * fs, off, v);
-                    sto(Lout + (size_t)k * fs, off, Lr[k]);
-                }
-            }
-            wave_lds_sync();
-            gram_tile_accum(tileA, acc1);
-            wave_lds_sync();
-#pragma unroll
-            for (int k = 0; k < KA; ++k)
-                tileA[k * CP_TS + lane] = (valid && (FULLK || k < K)) ? Lr[k] - mL : 0.0;
-            wave_lds_sync();
-            gram_tile_accum(tileA, acc2);
-            wave_lds_sync();
-#pragma unroll
-            for (int k = 0; k < KA; ++k) tileA[k * CP_TS + lane] = Lr[k];
+            // ---- phase 1: everything that couples the K images of this pixel ------------------------------------------
+            fused_phase1<S, FULLK, KA>(P, K, valid, off, lane, fs, y3in, pin, Lin, y3out, Lout, Wl, tileA, tileB, sigma, tau,
+                                       theta, maxs[PM_VL - CP_NSUM], acc1, acc2);
 
             // ---- phase 2: per image: primal step at the own pixel and at (i, j+1); (i +- 1, j) from a neighbour lane ------
             // where the i-neighbour's own-pixel result comes from: lane +- 1 of this step; for lane 63 the hand-over of the
@@ -354,6 +370,7 @@ struct EFusedArgs {
     int n;               // iteration: completes primal row n and dual row n, starts dual row n+1
     int check_stop;
     int norm21;          // F2 = mu*||.||_{2,1}: its conjugate's violation is max||v|| - mu (NNE/norm21.m:81-85), not relative
+    int reg;             // 1: NN-curvature (k_mf_fused_curv): F2, F2* and the stop rule belong to k_curv_fin, which runs after k_curv_y2
     double tol, mu1, mu2, sigma, tau, Ntot;
 };
 
@@ -412,8 +429,8 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
         double *hd = hist_d + (size_t)n * CP_HCOLS_MF, *hd1 = hist_d + (size_t)(n + 1) * CP_HCOLS_MF;
         // primal row n                                        chambolle_pock.m:168-171
         const double F1 = A.mu1 * sc[DS_F1], F2 = A.mu2 * sc[DS_F2];
-        hp[1] = F1; hp[2] = F2; hp[3] = 0.0; hp[4] = 0.0;
-        hp[0] = hp[4] + (F1 + F2 + 0.0);
+        hp[1] = F1; hp[3] = 0.0; hp[4] = 0.0;
+        if (A.reg == 0) { hp[2] = F2; hp[0] = hp[4] + (F1 + F2 + 0.0); }
         hp[5] = (sumS > nu) ? (sumS - nu) / nu : 0.0;          // nuclear_norm_constraint.m:55-59
         hp[6] = fmax(fabs(sc[DS_UX] / A.Ntot), fabs(sc[DS_UY] / A.Ntot));   // mean_zero_indicator.m:65
         // dual row n: G* part (F* part was stored one iteration earlier)     :173-176
@@ -425,16 +442,17 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
         hd[0] = -(hd[4] + (hd[1] + hd[2] + hd[3]));
         // dual row n+1: F* part of y_{n+1}
         hd1[1] = sc[DS_F1S];
-        hd1[2] = 0.0;
+        if (A.reg == 0) hd1[2] = 0.0;
         hd1[3] = nu * res[0];
         const double con1 = (sc[DM_Y1] > A.mu1) ? sc[DM_Y1] - A.mu1 : 0.0;
-        const double con2 = A.norm21 ? ((sc[DM_S1] > A.mu2) ? sc[DM_S1] - A.mu2 : 0.0)   // NNE/norm21.m:81-85
-                                     : fmax((sc[DM_S1] - A.mu2) / A.mu2, 0.0);           // NNE/pointwise_2x2_nn.m:52-57
+        const double con2 = (A.reg != 0) ? 0.0                                           // NNE/SSD.m: no constraint
+                            : A.norm21 ? ((sc[DM_S1] > A.mu2) ? sc[DM_S1] - A.mu2 : 0.0)   // NNE/norm21.m:81-85
+                                       : fmax((sc[DM_S1] - A.mu2) / A.mu2, 0.0);           // NNE/pointwise_2x2_nn.m:52-57
         hd1[5] = fmax(con1, con2);
         // mean of the next un-projected u
         ctrl->cn[0] = sc[DS_UX] / A.Ntot + A.tau * (sc[DS_SGX] / A.Ntot);
         ctrl->cn[1] = sc[DS_UY] / A.Ntot + A.tau * (sc[DS_SGY] / A.Ntot);
-        if (A.check_stop && n >= 4) {                          // chambolle_pock.m:142-153
+        if (A.check_stop && n >= 4 && A.reg == 0) {            // chambolle_pock.m:142-153
             bool ok = true;
             for (int r = n - 4; r <= n; ++r) {
                 const double *p_ = hist_p + (size_t)r * CP_HCOLS_MF, *d_ = hist_d + (size_t)r * CP_HCOLS_MF;

@@ -430,6 +430,10 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_eig(EigArgs A, const doub
             // mean(u - tau*(A'y)_u) = mean(u) + tau*mean(grad T' y1): D'y2 has zero mean because D*1 = 0
             ctrl->cn[0] = sc[DS_UX] / A.Ntot + A.tau * (sc[DS_SGX] / A.Ntot);
             ctrl->cn[1] = sc[DS_UY] / A.Ntot + A.tau * (sc[DS_SGY] / A.Ntot);
+            if (A.reg != 0) {   // curvature: (A'y)_u = -grad T' y1 + Lap y2, and mean(Lap y2) = sum(y2 * rowsum(Lap)) / N (dirichlet rows)
+                ctrl->cn[0] -= A.tau * (sc[DS_BSX] / A.Ntot);
+                ctrl->cn[1] -= A.tau * (sc[DS_BSY] / A.Ntot);
+            }
         }
         if (A.rp >= 0) {
             double *hp = hist_p + (size_t)A.rp * CP_HCOLS_MF;
