@@ -137,6 +137,15 @@ int cp_get_linearization(cp_handle h, double *T_u, double *grad, double *b);
  * (unit parity of a8-a18) and re-use a linearisation computed elsewhere.                  */
 int cp_set_linearization(cp_handle h, const double *T_u, const double *grad, const double *b);
 
+/* [img_u, dimg_u] = evaluate_displacement(img, h, u, omega, s_grid)  (IRE/evaluate_displacement.m:1-50) on its own, in
+ * full generality: img is m x n with spacing h; the k x l cell-centred grid over omega (NULL: [0, m*h1, 0, n*h2], :33-36)
+ * is displaced by u ((k*l) x 2, column-major; NULL: zero) and img interpolated there (bilinear, zero padding). k x l need
+ * not equal m x n: this is the reference's resampling facility (s_grid, :27-31; e.g. an upsampled copy of an image with
+ * u = NULL). img_u: k*l doubles; grad: (k*l) x 2 = the two diagonals of dimg_u (:47-48), or NULL. Host buffers in and
+ * out; stateless (allocates and frees its own device buffers). */
+int cp_evaluate_displacement(int32_t device, const double *img, int32_t m, int32_t n, const double *h, const double *u,
+                             const double *omega, int32_t k, int32_t l, double *img_u, double *grad);
+
 /* --- mf_nn only --------------------------------------------------------------------------
  * radius nu of the nuclear-norm ball (NNE/mf_nn_tv...:171-180 keeps the schedule on the host) */
 int cp_set_nu(cp_handle h, double nu);

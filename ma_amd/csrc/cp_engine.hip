@@ -1860,6 +1860,60 @@ extern "C" int cp_mg_power_start(cp_handle h, double *local_sumsq) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// IRE/evaluate_displacement.m in full generality: image m x n with spacing h, evaluated on a k x l cell-centred grid over
+// omega displaced by u -- the output resolution need not be the image's (s_grid, :27-31), which is how the reference's
+// resampling facility is used (e.g. an image upsampled with u = 0). One thread per output sample; coordinate arithmetic
+// in explicitly rounded operations as in k_mf_warp / k_pw_warp (floor() is the index logic).
+__global__ __launch_bounds__(CP_BLOCK) void k_eval_displacement(int mi, int ni, int k, int l, double om0, double om2, double hx,
+                                                                double hy, double inv_h1, double inv_h2,
+                                                                const double *__restrict__ img, const double *__restrict__ u,
+                                                                double *__restrict__ Tu, double *__restrict__ grad) {
+    const long long tot = (long long)k * l;
+    for (long long q = (long long)blockIdx.x * CP_BLOCK + threadIdx.x; q < tot; q += (long long)gridDim.x * CP_BLOCK) {
+        const int j = (int)(q / k), i = (int)(q - (long long)j * k);
+        const double ux = u ? u[q] : 0.0, uy = u ? u[tot + q] : 0.0;                       // u = [u_x(:), u_y(:)]  (:15)
+        const double px = __dadd_rn(__dadd_rn(om0, __dmul_rn(hx, (double)i + 0.5)), ux);   // IRE/cell_centered_grid.m:21-29, :43
+        const double py = __dadd_rn(__dadd_rn(om2, __dmul_rn(hy, (double)j + 0.5)), uy);
+        double val, dx, dy;
+        bilinear_tap(img, mi, ni, px, py, inv_h1, inv_h2, val, dx, dy);
+        Tu[q] = val;
+        if (grad) { grad[q] = dx; grad[tot + q] = dy; }
+    }
+}
+
+extern "C" int cp_evaluate_displacement(int32_t device, const double *img, int32_t m, int32_t n, const double *h,
+                                        const double *u, const double *omega, int32_t k, int32_t l, double *img_u,
+                                        double *grad) {
+    if (!img || !h || !img_u) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_evaluate_displacement needs img, h and img_u");
+    if (m < 1 || n < 1 || k < 1 || l < 1) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg image %d x %d, grid %d x %d", m, n, k, l);
+    if (!(h[0] > 0.0) || !(h[1] > 0.0)) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg grid spacing must be positive");
+    HIPCHK(hipSetDevice(device));
+    double om[4] = {0.0, m * h[0], 0.0, n * h[1]};                      // default region (:33-36)
+    if (omega) memcpy(om, omega, sizeof om);
+    const size_t ni_ = (size_t)m * n, no = (size_t)k * l;
+    double *d_img = nullptr, *d_u = nullptr, *d_T = nullptr, *d_g = nullptr;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc(&d_img, ni_ * sizeof(double)));
+        HIPCHK(hipMalloc(&d_T, no * sizeof(double)));
+        if (u) HIPCHK(hipMalloc(&d_u, 2 * no * sizeof(double)));
+        if (grad) HIPCHK(hipMalloc(&d_g, 2 * no * sizeof(double)));
+        HIPCHK(hipMemcpy(d_img, img, ni_ * sizeof(double), hipMemcpyHostToDevice));
+        if (u) HIPCHK(hipMemcpy(d_u, u, 2 * no * sizeof(double), hipMemcpyHostToDevice));
+        const int grid = (int)std::min<size_t>((no + CP_BLOCK - 1) / CP_BLOCK, 65536);
+        hipLaunchKernelGGL(k_eval_displacement, dim3(grid), dim3(CP_BLOCK), 0, nullptr, m, n, k, l, om[0], om[2],
+                           (om[1] - om[0]) / k, (om[3] - om[2]) / l, 1.0 / h[0], 1.0 / h[1], d_img, d_u, d_T, d_g);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(img_u, d_T, no * sizeof(double), hipMemcpyDeviceToHost));
+        if (grad) HIPCHK(hipMemcpy(grad, d_g, 2 * no * sizeof(double), hipMemcpyDeviceToHost));
+        return CP_OK;
+    };
+    const int rc = body();
+    for (double *p : {d_img, d_u, d_T, d_g})
+        if (p) hipFree(p);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Streaming copy: the practical HBM ceiling of this box next to the 8 TB/s of the data sheet (bench.py's
 // roofline.measured_copy_GBps). One element of VEC doubles per lane and step (8 or 16 bytes per lane), grid-stride,
 // nontemporal on both sides -- the access shape of the field kernels (8 B/lane) and the widest one (16 B/lane).

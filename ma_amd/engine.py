@@ -89,6 +89,7 @@ def _load():
         "cp_mg_power_start": [vp, dp],
         "cp_singular_values_static": [C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp],
         "cp_stream_copy_gbps": [C.c_int32, C.c_int64, C.c_int32, C.c_int32, dp],
+        "cp_evaluate_displacement": [C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, C.c_int32, dp, dp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -124,7 +125,7 @@ EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_im
             "cp_downsample", "cp_iterate", "cp_iterate_begin", "cp_iterate_steps", "cp_iterate_end", "cp_sync",
             "cp_kernel_time_ms", "cp_set_stream", "cp_mg_partial_len",
             "cp_mg_halo_len", "cp_mg_halo_pack", "cp_mg_halo_unpack", "cp_mg_state_pack", "cp_mg_state_unpack", "cp_mg_begin", "cp_mg_stage", "cp_mg_end",
-            "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start", "cp_singular_values_static", "cp_stream_copy_gbps"]
+            "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start", "cp_singular_values_static", "cp_stream_copy_gbps", "cp_evaluate_displacement"]
 
 BUF_X0, BUF_X1, BUF_P0, BUF_P1, BUF_XTMP = 0, 1, 2, 3, 4
 SEL_ALL, SEL_X_U, SEL_P_Y12, SEL_P_DY, SEL_P_Y2 = 0, 1, 2, 3, 4
@@ -383,3 +384,23 @@ def stream_copy_gbps(device=0, nbytes=1 << 31, lane_bytes=16, repeats=3):
     out = C.c_double()
     _chk(lib.cp_stream_copy_gbps(int(device), int(nbytes), int(lane_bytes), int(repeats), C.byref(out)))
     return out.value
+
+
+def evaluate_displacement(img, h, u=None, omega=None, s_grid=None, device=0, want_grad=True):
+    """[img_u, g] = evaluate_displacement(img, h, u, omega, s_grid)  (IRE/evaluate_displacement.m): img_u is k x l, g is
+    (k*l) x 2 (the reference wraps g into a sparse matrix, :47-48)"""
+    img = np.asarray(img, dtype=np.float64)
+    m, n = img.shape
+    k, l = (m, n) if s_grid is None else (int(s_grid[0]), int(s_grid[1]))
+    hh = np.ascontiguousarray(np.asarray(h, dtype=np.float64).reshape(2))
+    imgv = np.ascontiguousarray(img.reshape(-1, order="F"))
+    uv = None
+    if u is not None and np.size(u) > 1:
+        uv = np.ascontiguousarray(np.asarray(u, dtype=np.float64).reshape((k * l, 2), order="F").reshape(-1, order="F"))
+    elif u is not None and float(np.asarray(u).reshape(-1)[0]) != 0.0:
+        uv = np.full(2 * k * l, float(np.asarray(u).reshape(-1)[0]))
+    om = None if omega is None else np.ascontiguousarray(np.asarray(omega, dtype=np.float64).reshape(4))
+    out = np.empty(k * l)
+    g = np.empty(2 * k * l) if want_grad else None
+    _chk(lib.cp_evaluate_displacement(int(device), _dptr(imgv), m, n, _dptr(hh), _dptr(uv), _dptr(om), k, l, _dptr(out), _dptr(g)))
+    return out.reshape((k, l), order="F"), (None if g is None else g.reshape((k * l, 2), order="F"))

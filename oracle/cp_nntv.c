@@ -1,4 +1,4 @@
-/* TEST INFRASTRUCTURE ONLY -- CPU restatement (plain C + OpenMP) of the NN-TV hot path of roland1993/MA.
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement (plain C + OpenMP) of the NN-TV and NN-curvature hot paths of roland1993/MA.
  * PARITY UNPINNED: the reference is MATLAB source, cannot be run in this image and stores no golden vectors; this file
  * is checked against the numpy restatement (the oracle .py files, themselves pinned only by the reference's invariants) in
  * tests/test_oracle_c.py. Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may load it.
@@ -29,6 +29,8 @@ typedef struct {
     int m, n, K, linear;
     double ih1, ih2, mu1, mu2, nu;
     const double *g, *b;
+    int curv, neumann, nc;   /* curv: NNE/mf_nn_curvature_registration_no_ref_ml.m (A2 = discrete_laplacian, F2 = SSD(y2, 0));
+                                neumann: Laplacian boundary rows (else dirichlet); nc = blocks of y2 per image (4 | 2) */
 } prob_t;
 
 int nntv_threads(void) {
@@ -182,6 +184,15 @@ static inline double fd_adj(const double *w, long idx, long stride, int pos, int
     return r;
 }
 
+/* 5-point Laplacian of one field at pixel q = (i, j): a missing neighbour is the centre value (neumann, diagonal -1/h^2)
+ * or zero (dirichlet, diagonal -2/h^2)                                        NNE/discrete_laplacian.m:23-46 */
+static inline double lap5(const double *u, long q, int i, int j, int m, int n, int neumann, double ih1, double ih2) {
+    const double w0 = u[q], mis = neumann ? w0 : 0.0;
+    const double a0 = (i > 0) ? u[q - 1] : mis, a1 = (i < m - 1) ? u[q + 1] : mis;
+    const double a2 = (j > 0) ? u[q - m] : mis, a3 = (j < n - 1) ? u[q + m] : mis;
+    return (a0 + a1 - 2.0 * w0) * (ih1 * ih1) + (a2 + a3 - 2.0 * w0) * (ih2 * ih2);
+}
+
 /* y = A*x */
 static void apply_A(const prob_t *P, const double *x, double *y) {
     const int m = P->m, n = P->n, K = P->K;
@@ -197,12 +208,17 @@ static void apply_A(const prob_t *P, const double *x, double *y) {
             const double *ux = x + (long)(2 * k) * mn, *uy = ux + mn;
             const double *gx = P->g + (long)(2 * k) * mn, *gy = gx + mn;
             y[(long)k * mn + q] = -(gx[q] * ux[q] + gy[q] * uy[q]) + L[(long)k * mn + q];
-            double *y2 = y + kmn + (long)(4 * k) * mn;
-            y2[q] = fd(ux, q, 1, i, m, P->linear, P->ih1);
-            y2[mn + q] = fd(ux, q, m, j, n, P->linear, P->ih2);
-            y2[2 * mn + q] = fd(uy, q, 1, i, m, P->linear, P->ih1);
-            y2[3 * mn + q] = fd(uy, q, m, j, n, P->linear, P->ih2);
-            y[5 * kmn + (long)k * mn + q] = L[(long)k * mn + q] - mean;
+            double *y2 = y + kmn + (long)(P->nc * k) * mn;
+            if (P->curv) {
+                y2[q] = lap5(ux, q, i, j, m, n, P->neumann, P->ih1, P->ih2);
+                y2[mn + q] = lap5(uy, q, i, j, m, n, P->neumann, P->ih1, P->ih2);
+            } else {
+                y2[q] = fd(ux, q, 1, i, m, P->linear, P->ih1);
+                y2[mn + q] = fd(ux, q, m, j, n, P->linear, P->ih2);
+                y2[2 * mn + q] = fd(uy, q, 1, i, m, P->linear, P->ih1);
+                y2[3 * mn + q] = fd(uy, q, m, j, n, P->linear, P->ih2);
+            }
+            y[(1 + P->nc) * kmn + (long)k * mn + q] = L[(long)k * mn + q] - mean;
         }
     }
 }
@@ -215,17 +231,23 @@ static void apply_At(const prob_t *P, const double *y, double *x) {
     for (long q = 0; q < mn; ++q) {
         const int j = (int)(q / m), i = (int)(q - (long)j * m);
         double s3 = 0.0;
-        for (int k = 0; k < K; ++k) s3 += y[5 * kmn + (long)k * mn + q];
+        const long o3 = (1 + P->nc) * kmn;
+        for (int k = 0; k < K; ++k) s3 += y[o3 + (long)k * mn + q];
         const double mean3 = s3 / K;
         for (int k = 0; k < K; ++k) {
             const double y1 = y[(long)k * mn + q];
-            const double *y2 = y + kmn + (long)(4 * k) * mn;
+            const double *y2 = y + kmn + (long)(P->nc * k) * mn;
             const double *gx = P->g + (long)(2 * k) * mn, *gy = gx + mn;
-            x[(long)(2 * k) * mn + q] = -gx[q] * y1 + (fd_adj(y2, q, 1, i, m, P->linear, P->ih1) +
-                                                       fd_adj(y2 + mn, q, m, j, n, P->linear, P->ih2));
-            x[(long)(2 * k + 1) * mn + q] = -gy[q] * y1 + (fd_adj(y2 + 2 * mn, q, 1, i, m, P->linear, P->ih1) +
-                                                           fd_adj(y2 + 3 * mn, q, m, j, n, P->linear, P->ih2));
-            x[2 * kmn + (long)k * mn + q] = y1 + (y[5 * kmn + (long)k * mn + q] - mean3);
+            if (P->curv) {   /* the Laplacian is symmetric */
+                x[(long)(2 * k) * mn + q] = -gx[q] * y1 + lap5(y2, q, i, j, m, n, P->neumann, P->ih1, P->ih2);
+                x[(long)(2 * k + 1) * mn + q] = -gy[q] * y1 + lap5(y2 + mn, q, i, j, m, n, P->neumann, P->ih1, P->ih2);
+            } else {
+                x[(long)(2 * k) * mn + q] = -gx[q] * y1 + (fd_adj(y2, q, 1, i, m, P->linear, P->ih1) +
+                                                           fd_adj(y2 + mn, q, m, j, n, P->linear, P->ih2));
+                x[(long)(2 * k + 1) * mn + q] = -gy[q] * y1 + (fd_adj(y2 + 2 * mn, q, 1, i, m, P->linear, P->ih1) +
+                                                               fd_adj(y2 + 3 * mn, q, m, j, n, P->linear, P->ih2));
+            }
+            x[2 * kmn + (long)k * mn + q] = y1 + (y[o3 + (long)k * mn + q] - mean3);
         }
     }
 }
@@ -238,15 +260,19 @@ static void primal_row(const prob_t *P, const double *x, const double *y, double
     for (long e = 0; e < kmn; ++e) {
         f1 += fabs(y[e] - P->b[e]);                                  /* NNE/SAD.m:54 */
         const long k = e / mn, q = e - k * mn;
-        const double *y2 = y + kmn + 4 * k * mn;
-        double sig[2];
-        svd2(y2[q], y2[mn + q], y2[2 * mn + q], y2[3 * mn + q], sig, NULL, NULL);
-        f2 += sig[0] + sig[1];                                       /* NNE/pointwise_2x2_nn.m:32 */
+        const double *y2 = y + kmn + P->nc * k * mn;
+        if (P->curv) {
+            f2 += y2[q] * y2[q] + y2[mn + q] * y2[mn + q];           /* NNE/SSD.m:48 (g = 0) */
+        } else {
+            double sig[2];
+            svd2(y2[q], y2[mn + q], y2[2 * mn + q], y2[3 * mn + q], sig, NULL, NULL);
+            f2 += sig[0] + sig[1];                                   /* NNE/pointwise_2x2_nn.m:32 */
+        }
         sx += x[2 * k * mn + q];
         sy += x[(2 * k + 1) * mn + q];
     }
-    const double F1 = P->mu1 * f1, F2 = P->mu2 * f2;
-    const double sS = nuc_of_BL(y + 5 * kmn, mn, P->K);
+    const double F1 = P->mu1 * f1, F2 = P->curv ? P->mu2 * 0.5 * f2 : P->mu2 * f2;
+    const double sS = nuc_of_BL(y + (1 + P->nc) * kmn, mn, P->K);
     row[1] = F1; row[2] = F2; row[3] = 0.0; row[4] = 0.0;
     row[0] = row[4] + (F1 + F2 + 0.0);                               /* chambolle_pock.m:170-171 */
     row[5] = (sS > P->nu) ? (sS - P->nu) / P->nu : 0.0;              /* nuclear_norm_constraint.m:55-59 */
@@ -256,20 +282,25 @@ static void primal_row(const prob_t *P, const double *x, const double *y, double
 /* dual row: F*(y) values, G*(-A'y), violations; w = A'*y given                         chambolle_pock.m:239-243 */
 static void dual_row(const prob_t *P, const double *y, const double *w, double *row) {
     const long mn = (long)P->m * P->n, kmn = mn * P->K;
-    double f1s = 0.0, y1max = 0.0, s1max = 0.0, swx = 0.0;
-#pragma omp parallel for reduction(+ : f1s, swx) reduction(max : y1max, s1max) schedule(static)
+    double f1s = 0.0, f2s = 0.0, y1max = 0.0, s1max = 0.0, swx = 0.0;
+#pragma omp parallel for reduction(+ : f1s, f2s, swx) reduction(max : y1max, s1max) schedule(static)
     for (long e = 0; e < kmn; ++e) {
         f1s += y[e] * P->b[e];                                       /* NNE/SAD.m:83 */
         y1max = fmax(y1max, fabs(y[e]));
         const long k = e / mn, q = e - k * mn;
-        const double *y2 = y + kmn + 4 * k * mn;
-        double sig[2];
-        svd2(y2[q], y2[mn + q], y2[2 * mn + q], y2[3 * mn + q], sig, NULL, NULL);
-        s1max = fmax(s1max, sig[0]);
+        const double *y2 = y + kmn + P->nc * k * mn;
+        if (P->curv) {
+            const double z0 = y2[q] / P->mu2, z1 = y2[mn + q] / P->mu2;
+            f2s += z0 * z0 + z1 * z1;                                /* NNE/SSD.m:66-67 (g = 0) */
+        } else {
+            double sig[2];
+            svd2(y2[q], y2[mn + q], y2[2 * mn + q], y2[3 * mn + q], sig, NULL, NULL);
+            s1max = fmax(s1max, sig[0]);
+        }
         swx += -w[2 * k * mn + q];
     }
     double S[KMAX], V[KMAX][KMAX], smax = 0.0;
-    sv_of(y + 5 * kmn, mn, P->K, S, V);
+    sv_of(y + (1 + P->nc) * kmn, mn, P->K, S, V);
     for (int i = 0; i < P->K; ++i) smax = fmax(smax, S[i]);
     const double mwx = swx / (double)kmn;                            /* x-mean for both, mean_zero_indicator.m:78,81 */
     double dmax = 0.0, lmax = 0.0;
@@ -279,10 +310,10 @@ static void dual_row(const prob_t *P, const double *y, const double *w, double *
         dmax = fmax(dmax, fmax(fabs(-w[2 * k * mn + q] - mwx), fabs(-w[(2 * k + 1) * mn + q] - mwx)));
         lmax = fmax(lmax, fabs(w[2 * kmn + e]));                     /* zero_function.m:32 */
     }
-    row[1] = f1s; row[2] = 0.0; row[3] = P->nu * smax;               /* nuclear_norm_constraint.m:89 */
+    row[1] = f1s; row[2] = P->curv ? P->mu2 * (0.5 * f2s) : 0.0; row[3] = P->nu * smax;   /* nuclear_norm_constraint.m:89 */
     row[4] = 0.0;
     const double con1 = (y1max > P->mu1) ? y1max - P->mu1 : 0.0;     /* SAD.m:77-81 */
-    const double con2 = fmax((s1max - P->mu2) / P->mu2, 0.0);        /* pointwise_2x2_nn.m:56 */
+    const double con2 = P->curv ? 0.0 : fmax((s1max - P->mu2) / P->mu2, 0.0);   /* pointwise_2x2_nn.m:56 | SSD: none */
     row[5] = fmax(con1, con2);
     row[6] = fmax(dmax, lmax);
     row[0] = -(row[4] + (row[1] + row[2] + row[3]));                 /* chambolle_pock.m:175-176 */
@@ -298,9 +329,15 @@ static void prox_Fstar(const prob_t *P, double *y, double sigma) {
         const double Ls = y[e] / sigma, thr = (1.0 / sigma) * P->mu1, dd = Ls - P->b[e];
         const double prox = (dd > thr) ? (Ls - thr) : ((dd < -thr) ? (Ls + thr) : P->b[e]);
         y[e] = y[e] - sigma * prox;
-        /* pointwise 2x2 nuclear norm*: M - sigma*SVT_{mu/sigma}(M/sigma)   pointwise_2x2_nn.m:46-48, :16-24 */
         const long k = e / mn, q = e - k * mn;
-        double *y2 = y + kmn + 4 * k * mn;
+        double *y2 = y + kmn + P->nc * k * mn;
+        if (P->curv) {   /* SSD*, g = 0: x - tau*((x/tau)/(1 + lambda/tau))              NNE/SSD.m:60-61 with :43 */
+            const double den = 1.0 + P->mu2 * (1.0 / sigma);
+            y2[q] = y2[q] - sigma * ((y2[q] * (1.0 / sigma)) / den);
+            y2[mn + q] = y2[mn + q] - sigma * ((y2[mn + q] * (1.0 / sigma)) / den);
+            continue;
+        }
+        /* pointwise 2x2 nuclear norm*: M - sigma*SVT_{mu/sigma}(M/sigma)   pointwise_2x2_nn.m:46-48, :16-24 */
         const double a = y2[q] / sigma, c = y2[mn + q] / sigma, b = y2[2 * mn + q] / sigma, d = y2[3 * mn + q] / sigma;
         double sig[2], U[4], V[4];
         svd2(a, c, b, d, sig, U, V);
@@ -310,7 +347,7 @@ static void prox_Fstar(const prob_t *P, double *y, double sigma) {
         y2[q] -= sigma * r11; y2[mn + q] -= sigma * r21; y2[2 * mn + q] -= sigma * r12; y2[3 * mn + q] -= sigma * r22;
     }
     /* nuclear-norm ball*: U diag(S - mu*P_l1(S/mu)) V' = Y (I - V diag(d) V'), mu = nu*sigma   :72-79 */
-    double *y3 = y + 5 * kmn, S[KMAX], V[KMAX][KMAX], z[KMAX], Pz[KMAX], W[KMAX][KMAX];
+    double *y3 = y + (1 + P->nc) * kmn, S[KMAX], V[KMAX][KMAX], z[KMAX], Pz[KMAX], W[KMAX][KMAX];
     sv_of(y3, mn, K, S, V);
     const double mu_ = P->nu * sigma;
     for (int i = 0; i < K; ++i) z[i] = S[i] / mu_;
@@ -332,12 +369,12 @@ static void prox_Fstar(const prob_t *P, double *y, double sigma) {
 
 /* Runs at most max_iter iterations from (x, y); histories are (max_iter+1) x 7 row-major; returns the number of rows
  * filled (iterations + 1). tol < 0 disables the stop rule. */
-int nntv_chambolle_pock(int m, int n, int K, int linear, double h1, double h2, double mu, double nu, double theta,
-                        double tau, double sigma, int max_iter, double tol, const double *g, const double *b,
-                        double *x, double *y, double *hist_p, double *hist_d) {
+static int nn_chambolle_pock(int curv, int bc, int m, int n, int K, double h1, double h2, double mu, double nu, double theta,
+                            double tau, double sigma, int max_iter, double tol, const double *g, const double *b,
+                            double *x, double *y, double *hist_p, double *hist_d) {
     if (K < 2 || K > KMAX) return -1;
-    prob_t P = {m, n, K, linear, 1.0 / h1, 1.0 / h2, h1 * h2, mu * (h1 * h2), nu, g, b};
-    const long mn = (long)m * n, kmn = mn * K, nx = 3 * kmn, ny = 6 * kmn;
+    prob_t P = {m, n, K, bc == 1, 1.0 / h1, 1.0 / h2, h1 * h2, mu * (h1 * h2), nu, g, b, curv, bc == 0, curv ? 2 : 4};
+    const long mn = (long)m * n, kmn = mn * K, nx = 3 * kmn, ny = (2 + P.nc) * kmn;
     double *xbar = malloc(sizeof(double) * nx), *xold = malloc(sizeof(double) * nx), *w = malloc(sizeof(double) * nx);
     double *t = malloc(sizeof(double) * ny);
     if (!xbar || !xold || !w || !t) return -2;
@@ -390,4 +427,19 @@ int nntv_chambolle_pock(int m, int n, int K, int linear, double h1, double h2, d
     }
     free(xbar); free(xold); free(w); free(t);
     return i + 1;
+}
+
+/* NN-TV: bc 0 = neumann, 1 = linear (kept signature: linear flag) */
+int nntv_chambolle_pock(int m, int n, int K, int linear, double h1, double h2, double mu, double nu, double theta,
+                        double tau, double sigma, int max_iter, double tol, const double *g, const double *b,
+                        double *x, double *y, double *hist_p, double *hist_d) {
+    return nn_chambolle_pock(0, linear ? 1 : 0, m, n, K, h1, h2, mu, nu, theta, tau, sigma, max_iter, tol, g, b, x, y, hist_p, hist_d);
+}
+/* NN-curvature (NNE/mf_nn_curvature_registration_no_ref_ml.m:182-202,230-332): y = [y1 (K mn); per image (Lap ux; Lap uy)
+ * (2 K mn); y3 (K mn)]; bc 0 = neumann, 2 = dirichlet (NNE/discrete_laplacian.m:25-28) */
+int nncurv_chambolle_pock(int m, int n, int K, int bc, double h1, double h2, double mu, double nu, double theta,
+                          double tau, double sigma, int max_iter, double tol, const double *g, const double *b,
+                          double *x, double *y, double *hist_p, double *hist_d) {
+    if (bc != 0 && bc != 2) return -3;
+    return nn_chambolle_pock(1, bc, m, n, K, h1, h2, mu, nu, theta, tau, sigma, max_iter, tol, g, b, x, y, hist_p, hist_d);
 }

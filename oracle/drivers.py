@@ -119,7 +119,8 @@ def mf_nn_G(x, s, conjugate_flag, nargout):
     return a1 + a2, max(c1, c2), None
 
 
-def mf_nn_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start, keep=None, single_level=False):
+def mf_nn_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start, keep=None, single_level=False,
+                                 max_levels=None):
     """[u, L, SV_history] = mf_nn_{tv,curvature}_registration_no_ref_ml(img, optPara).
 
     `keep` (dict) receives diagnostics per (lev, o): nu, tau, norm estimate, histories.
@@ -144,6 +145,8 @@ def mf_nn_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_star
     nu = None
     ncomp = 6 if reg == "tv" else 4
     for lev in range(numLevels):
+        if max_levels is not None and lev >= max_levels:     # test aid: stop after the coarsest levels (full-size checks)
+            break
         m, n = ML[0][lev].shape
         h_grid = np.array([(omega[1] - omega[0]) / m, (omega[3] - omega[2]) / n])   # (:88)
         theta = optPara["theta"]

@@ -180,7 +180,7 @@ def pairwise_e2e(png):
         F = lambda v, c, nargout: px.TV_registration(v, sigma, c, nargout)
         u0, v0 = np.zeros(2 * m * n), np.zeros(4 * m * n)
         keep_steps = (0, 2, 20)
-        energies = []
+        energies, unorm, traj = [], [], []
         for s in range(steps):
             G = lambda u, c, nargout, u0_=u0.copy(): Gfun(u, u0_, T, R, (1.0, 1.0), lam, tau, c, nargout)
             xs, ys, ph, dh = cp_ref(F, G, K, u0, v0, 1.0, tau, sigma, iters)
@@ -192,9 +192,26 @@ def pairwise_e2e(png):
                 out[f"{tag}_s{s}_ph"] = ph
                 out[f"{tag}_s{s}_dh"] = dh
             energies.append([ph[-1, 0], dh[-1, 0], ph.shape[0]])
+            traj.append(xs.copy())
             u0, v0 = xs, ys
         out[f"{tag}_energies"] = np.array(energies)
         out[f"{tag}_par"] = np.array([lam, tau, iters, steps])
+        out[f"{tag}_u_final"] = traj[-1]
+        # Sensitivity of the free-running script: the same script with the template perturbed by ONE ulp in every pixel
+        # (up, then down). Every re-linearisation re-selects interpolation cells (floor, IRE/bilinear_interpolation.m:42)
+        # and the SAD prox divides by |grad T|^2 (PDO/SAD_registration.m:74-75), so after a few outer steps two correct
+        # implementations are 1e-4 .. 5e-3 apart. Column 0: relative distance of u after step s, column 1: relative
+        # difference of the final primal energy of step s (maximum over the two perturbations).
+        sens = np.zeros((steps, 2))
+        for Tp in (np.nextafter(T, 2.0), np.nextafter(T, -1.0)):
+            u0, v0 = np.zeros(2 * m * n), np.zeros(4 * m * n)
+            for s in range(steps):
+                G = lambda u, c, nargout, u0_=u0.copy(): Gfun(u, u0_, Tp, R, (1.0, 1.0), lam, tau, c, nargout)
+                xs, ys, ph, dh = cp_ref(F, G, K, u0, v0, 1.0, tau, sigma, iters)
+                sens[s, 0] = max(sens[s, 0], np.linalg.norm(xs - traj[s]) / np.linalg.norm(traj[s]))
+                sens[s, 1] = max(sens[s, 1], abs(ph[-1, 0] - energies[s][0]) / abs(energies[s][0]))
+                u0, v0 = xs, ys
+        out[f"{tag}_sens"] = sens
     np.savez_compressed(os.path.join(HERE, "pairwise_e2e.npz"), **out)
 
 

@@ -200,3 +200,78 @@ def test_single_level_drivers_fixture(golden_dir):
         np.testing.assert_allclose(kk["primal_history"], f[f"var_ph_{o}"], rtol=1e-8, atol=1e-9)
         np.testing.assert_allclose(kk["dual_history"], f[f"var_dh_{o}"], rtol=1e-8, atol=1e-9)
         assert _rel(uv[o], f[f"var_u_{o}"]) < 1e-9, o
+
+
+@pytest.mark.parametrize("tag,a,b,term", [("tvl1_rect", "rect_1", "rect_2", "SAD"),
+                                          ("tvl2_rir", "rect_in_rect_1", "rect_in_rect_2", "SSD"),
+                                          ("tvl1_slide", "sliding_rect_1", "sliding_rect_2", "SAD")])
+def test_pairwise_free_running_script_fixture(golden_dir, tag, a, b, term):
+    """The whole script of PDO/test_TV_L1_registration.m:94-122 / test_TV_L2_registration.m (40 outer steps, warm starts,
+    the reference's parameter sets :28-54) free-running on the device, against the stored energies of every outer step.
+    The script is ill-conditioned across outer steps: `{tag}_sens` holds what ONE ulp on the template does to the oracle
+    itself (tests/golden/make_golden.py) -- nothing for a number of steps, then a jump to 1e-4 .. 5e-3 when the first pixel
+    re-selects its interpolation cell. Bar: 1e-10 on every step before that onset; afterwards the engine may be as far
+    from the oracle as the perturbed oracle is (2 x the largest distance seen), never further."""
+    from ma_amd import engine as E
+    from ma_amd.drivers import normalize
+    f = _load(golden_dir, "pairwise_e2e.npz")
+    png = _load(golden_dir, "data_png.npz")
+    R = normalize(png[a].astype(np.float64))
+    T = normalize(png[b].astype(np.float64))
+    m, n = R.shape
+    lam, tau, iters, steps = f[f"{tag}_par"]
+    sigma = (1 - 1e-4) / (8 * tau)
+    en, sens = f[f"{tag}_energies"], f[f"{tag}_sens"]
+    onset = int(np.argmax(sens[:, 0] > 1e-9)) if (sens[:, 0] > 1e-9).any() else int(steps)
+    assert 1 <= onset                                        # the first outer step is always well conditioned
+    loose_u, loose_e = 2.0 * sens[:, 0].max(), 2.0 * sens[:, 1].max()
+    eng = E.Engine(E.MODEL_TV_L1_REG if term == "SAD" else E.MODEL_TV_L2_REG, m, n, lam=float(lam))
+    eng.set_images(_vecF(T), _vecF(R))
+    worst_pre, worst_post = 0.0, 0.0
+    for s in range(int(steps)):
+        eng.linearize()                                      # u0 <- u_star (:119-120)
+        eng.solve(1.0, float(tau), sigma, int(iters), 1e-3)
+        ph, _ = eng.history()
+        assert ph.shape[0] == int(en[s, 2]), s               # iteration counts of every outer step
+        de = abs(ph[-1, 0] - en[s, 0]) / abs(en[s, 0])
+        du = None
+        if f"{tag}_s{s}_u" in f:
+            du = _rel(eng.primal(), f[f"{tag}_s{s}_u"])
+        elif s == int(steps) - 1:
+            du = _rel(eng.primal(), f[f"{tag}_u_final"])
+        if s < onset - 1:
+            assert de <= TOL and (du is None or du <= TOL), (s, de, du)
+            worst_pre = max(worst_pre, de, du or 0.0)
+        else:
+            assert de <= max(TOL, loose_e) and (du is None or du <= max(TOL, loose_u)), (s, de, du, loose_e, loose_u)
+            worst_post = max(worst_post, de, du or 0.0)
+    eng.close()
+    print(f"{tag}: onset of the oracle's own 1-ulp divergence at outer step {onset}; engine-oracle gap before {worst_pre:.1e}, "
+          f"after {worst_post:.1e} (bound {max(loose_e, loose_u):.1e})")
+
+
+def test_evaluate_displacement_s_grid_fixture(golden_dir):
+    """IRE/evaluate_displacement.m with an output resolution different from the image's (s_grid, :27-31): Data/rect_2.png
+    (70 x 55) resampled to 96 x 80 with u = 0 -- the recipe of BASELINE config 2 -- against the stored oracle output, and a
+    displaced coarse grid against the oracle directly"""
+    from ma_amd import engine as E
+    from oracle import operators as oo
+    f = _load(golden_dir, "warp.npz")
+    T = f["T"]
+    m, n = T.shape
+    Tup, _ = E.evaluate_displacement(T, (1.0, 1.0), None, [0.0, float(m), 0.0, float(n)], (96, 80))
+    np.testing.assert_allclose(Tup, f["Tup"], rtol=0, atol=1e-15)
+    assert np.array_equal(Tup == 0.0, f["Tup"] == 0.0)
+    rng = np.random.default_rng(5)
+    u = 4.0 * rng.standard_normal((33 * 41, 2))
+    u[:20] -= 90.0
+    Tr, gr = oo.evaluate_displacement(T, (2.0, 0.5), u, [1.0, 120.0, -3.0, 30.0], (33, 41))
+    Tg, gg = E.evaluate_displacement(T, (2.0, 0.5), u, [1.0, 120.0, -3.0, 30.0], (33, 41))
+    np.testing.assert_allclose(Tg, Tr, rtol=0, atol=5e-15)        # products contracted to fma on the device: a few ulp
+    np.testing.assert_allclose(gg, gr, rtol=0, atol=5e-14)
+    assert np.array_equal(Tg == 0.0, Tr == 0.0)                   # the index / validity logic is exact
+    # default region and default grid: the plain warp of the image at its own resolution
+    Tr, gr = oo.evaluate_displacement(T, (1.0, 1.0), f["u"])
+    Tg, gg = E.evaluate_displacement(T, (1.0, 1.0), f["u"])
+    np.testing.assert_allclose(Tg, Tr, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(gg, gr, rtol=0, atol=1e-14)

@@ -95,3 +95,31 @@ def test_single_level_fixture_and_its_functional(golden_dir):
         assert np.array_equal(prox[:k * mn], px.SAD(y[:k * mn], b, 1.0, sigma, conj, 3)[2])
         for j in range(k):
             assert np.array_equal(prox[k * mn + j * 4 * mn: k * mn + (j + 1) * 4 * mn], px.norm21(Y2[:, j], mu, sigma, conj, 3)[2])
+
+
+def test_pairwise_script_sensitivity_is_what_the_fixture_says(golden_dir):
+    """The free-running TV-L1 script is ill-conditioned across outer steps: a ONE-ulp perturbation of the template leaves
+    the first outer steps untouched (1e-15) and then moves the iterate by 1e-4 .. 5e-3 -- so two correct implementations
+    cannot agree to 1e-10 over the whole script, and the GPU test bounds the engine's distance by this envelope
+    (tests/test_gpu_golden.py::test_pairwise_free_running_script_fixture). Re-runs the first outer steps of the perturbed
+    oracle and checks them against the stored envelope."""
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    f = _load(golden_dir, "pairwise_e2e.npz")
+    png = _load(golden_dir, "data_png.npz")
+    for tag in ("tvl1_rect", "tvl1_slide"):
+        sens = f[f"{tag}_sens"]
+        onset = int(np.argmax(sens[:, 0] > 1e-9))
+        assert onset >= 2 and sens[:onset, 0].max() < 1e-13 and sens[onset:, 0].max() > 1e-5
+    R = od.normalize(png["sliding_rect_1"].astype(float))
+    T = od.normalize(png["sliding_rect_2"].astype(float))
+    lam, tau, iters, _ = f["tvl1_slide_par"]
+    m, n = R.shape
+    K = oo.pairwise_gradient(m, n, (1.0, 1.0), 2)
+    sigma = (1 - 1e-4) / (8 * tau)
+    F = lambda v, c, nargout: px.TV_registration(v, sigma, c, nargout)
+    Tp = np.nextafter(T, 2.0)
+    u0, v0 = np.zeros(2 * m * n), np.zeros(4 * m * n)
+    for s in range(3):
+        G = lambda u, c, nargout, u0_=u0.copy(): px.SAD_registration(u, u0_, Tp, R, (1.0, 1.0), lam, tau, c, nargout)
+        u0, v0, ph, _ = cp_ref(F, G, K, u0, v0, 1.0, tau, sigma, int(iters))
+        assert abs(ph[-1, 0] - f["tvl1_slide_energies"][s, 0]) <= 1e-12 * abs(ph[-1, 0])      # still on the unperturbed trajectory
