@@ -219,7 +219,10 @@ int cp_stream_copy_gbps(int32_t device, int64_t bytes, int32_t lane_bytes, int32
  * (e.g. torch's current stream), so the caller's collectives on that stream are ordered with them.   */
 enum { CP_BUF_X0 = 0, CP_BUF_X1 = 1, CP_BUF_P0 = 2, CP_BUF_P1 = 3, CP_BUF_XTMP = 4 };
 enum { CP_SEL_ALL = 0, CP_SEL_X_U = 1, CP_SEL_P_Y12 = 2, CP_SEL_P_DY = 3,
-       CP_SEL_P_Y2 = 4      /* all y2 fields (4K TV, 2K curvature): split passes, both directions */ };
+       CP_SEL_P_Y2 = 4,     /* all y2 fields (4K TV, 2K curvature): both directions */
+       /* the same fields of a VECTOR of the power iteration (CP_BUF_X1 / CP_BUF_P1 / CP_BUF_XTMP between cp_mg_power_start
+        * and the next solve): doubles in every storage mode, where the state selections above move floats in the fp32 mode */
+       CP_SEL_VEC_X_U = 5, CP_SEL_VEC_P_DY = 6, CP_SEL_VEC_P_Y2 = 7 };
 enum { CP_STAGE_DUAL0 = 0,   /* dual step 1 alone (first kernel of a solve) + local reduction -> red      */
        CP_STAGE_EIG0 = 1,    /* eigensolve on the gathered partials of DUAL0                               */
        CP_STAGE_FUSED = 2,   /* k_mf_fused_tv for iteration n + local reduction -> red                     */
@@ -228,10 +231,17 @@ enum { CP_STAGE_DUAL0 = 0,   /* dual step 1 alone (first kernel of a solve) + lo
        CP_STAGE_APPLY_AT = 5, /* power iteration: XTMP = A' * P1, local sum of squares -> red[0]; swaps X1/XTMP */
        /* split passes (NN-curvature; also NN-TV): iteration n = DUAL -> gather -> EIG -> halo(y2) -> PRIMAL -> gather
         * -> FIN -> halo(u)                                                                                    */
-       CP_STAGE_SPLIT_DUAL = 6, CP_STAGE_SPLIT_EIG = 7, CP_STAGE_SPLIT_PRIMAL = 8, CP_STAGE_SPLIT_FIN = 9 };
+       CP_STAGE_SPLIT_DUAL = 6, CP_STAGE_SPLIT_EIG = 7, CP_STAGE_SPLIT_PRIMAL = 8, CP_STAGE_SPLIT_FIN = 9,
+       /* history row 0 = primal_objective(x0), dual_objective(y0) (PDO/chambolle_pock.m:89-106) on slabs:
+        * ROW0_DUAL -> gather -> ROW0_EIG, ROW0_PRIMAL -> gather -> ROW0_FIN (monitor passes: the state is not touched) */
+       CP_STAGE_ROW0_DUAL = 10, CP_STAGE_ROW0_EIG = 11, CP_STAGE_ROW0_PRIMAL = 12, CP_STAGE_ROW0_FIN = 13,
+       /* NN-curvature in two field passes (cp_mfnn_curv.cuh): iteration n = CURV_P -> gather -> EFUSED, halo(u_n, both
+        * directions) -> CURV_Y2 -> gather -> CURV_FIN (stop rule), halo(y2_{n+1}, both directions) */
+       CP_STAGE_CURV_P = 14, CP_STAGE_CURV_Y2 = 15, CP_STAGE_CURV_FIN = 16 };
 int cp_set_stream(cp_handle h, void *hip_stream);          /* NULL = the handle's own stream            */
 int64_t cp_mg_partial_len(void);                           /* doubles per reduced partial vector        */
-int64_t cp_mg_halo_len(cp_handle h, int sel);              /* doubles per packed halo column            */
+int64_t cp_mg_halo_len(cp_handle h, int sel);              /* doubles the message buffer of one packed halo column needs
+                                                              (fp32 mode: the state selections pack floats, two per double) */
 /* column = 0: first owned column, 1: last owned column -> dev_out                                      */
 int cp_mg_halo_pack(cp_handle h, int buf, int sel, int column, double *dev_out);
 /* side = 0: left halo column, 1: right halo column <- dev_in                                           */

@@ -281,9 +281,9 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         h->d.omega[3] = h->d.n_global * d.h[1];
     }
     if (pw && (h->d.n_global != d.n)) { delete h; CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported slabs for pairwise models"); }
-    if ((d.flags & CP_FLAG_FP32) && (var || (mf && h->d.n_global != d.n))) {
+    if ((d.flags & CP_FLAG_FP32) && var) {
         delete h;
-        CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported the fp32 mode covers the pairwise and mf_nn models on a full domain");
+        CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported the fp32 mode covers the pairwise and mf_nn models");
     }
     h->fp32 = (d.flags & CP_FLAG_FP32) != 0;
     h->mf = mf;
@@ -1328,15 +1328,17 @@ extern "C" int cp_get_history(cp_handle h, double *primal_history, double *dual_
 }
 
 // ------------------------------------------------------------------------------------------------
+// joff: global index of the fine slab's first column minus twice that of the coarse slab's (0 on a full domain)
 template <typename S>
-__global__ void k_prolong(int m, int n, int fs, int ml, int nlw, int fsl, int nfields, double factor,
+__global__ void k_prolong(int m, int n, int fs, int ml, int nlw, int fsl, int nfields, double factor, int jf_off, int jc_off,
                           const S *__restrict__ xl, S *__restrict__ xh) {
     const long long tot = (long long)m * n * nfields;
     for (long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot; gid += (long long)gridDim.x * CP_BLOCK) {
         const int f = (int)(gid / ((long long)m * n)), q = (int)(gid - (long long)f * m * n);
         const int j = q / m, i = q - j * m;
+        const int jc = ((jf_off + j) >> 1) - jc_off;           // local column of the coarse handle
         // kron(x_low, ones(2)) cropped to (1:m, 1:n)          NNE/mf_nn_tv...:113-119
-        xh[(size_t)f * fs + m + q] = (S)(factor * (double)xl[(size_t)f * fsl + ml + (size_t)(j >> 1) * ml + (i >> 1)]);
+        xh[(size_t)f * fs + m + q] = (S)(factor * (double)xl[(size_t)f * fsl + ml + (size_t)jc * ml + (i >> 1)]);
     }
 }
 
@@ -1344,8 +1346,16 @@ extern "C" int cp_prolong(cp_handle coarse, cp_handle fine, double factor) {
     if (!coarse || !fine) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null handle");
     if (coarse->nxf != fine->nxf || coarse->batch != fine->batch || coarse->d.device != fine->d.device)
         CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg handles do not match");
-    if (fine->m > 2 * coarse->m || fine->nl > 2 * coarse->nl)
+    if (fine->m > 2 * coarse->m || fine->d.n_global > 2 * coarse->d.n_global)
         CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg fine level larger than twice the coarse level");
+    // row slabs: every owned column of the fine handle needs its parent column among the coarse handle's owned columns
+    // (a full coarse handle serves any fine slab; slab -> slab needs fine boundaries = twice the coarse ones)
+    {
+        const int c_lo = fine->d.j_offset >> 1, c_hi = (fine->d.j_offset + fine->nl - 1) >> 1;
+        if (c_lo < coarse->d.j_offset || c_hi >= coarse->d.j_offset + coarse->nl)
+            CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg coarse columns [%d, %d] needed, the coarse handle owns [%d, %d)", c_lo, c_hi,
+                    coarse->d.j_offset, coarse->d.j_offset + coarse->nl);
+    }
     HIPCHK(hipSetDevice(fine->d.device));
     CP_NOT_ITERATING(coarse);
     CP_NOT_ITERATING(fine);
@@ -1354,10 +1364,11 @@ extern "C" int cp_prolong(cp_handle coarse, cp_handle fine, double factor) {
     const int nf = fine->nxf * fine->batch;
     if (fine->fp32)
         hipLaunchKernelGGL((k_prolong<float>), dim3(2048), dim3(CP_BLOCK), 0, fine->stream, fine->m, fine->nl, fine->fs, coarse->m,
-                           coarse->nl, coarse->fs, nf, factor, (const float *)coarse->X[0], (float *)fine->X[0]);
+                           coarse->nl, coarse->fs, nf, factor, fine->d.j_offset, coarse->d.j_offset, (const float *)coarse->X[0],
+                           (float *)fine->X[0]);
     else
         hipLaunchKernelGGL((k_prolong<double>), dim3(2048), dim3(CP_BLOCK), 0, fine->stream, fine->m, fine->nl, fine->fs, coarse->m,
-                           coarse->nl, coarse->fs, nf, factor, coarse->X[0], fine->X[0]);
+                           coarse->nl, coarse->fs, nf, factor, fine->d.j_offset, coarse->d.j_offset, coarse->X[0], fine->X[0]);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(fine->P[0], 0, sizeof(double) * fine->pN, fine->stream));   // p = zeros (:122)
     HIPCHK(hipStreamSynchronize(fine->stream));
@@ -1534,15 +1545,18 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_reduce_local(int nblk, co
     }
 }
 
+// S = element type of the buffer: the storage type of the state (double, or float in the fp32 mode), double for the
+// vectors of the power iteration
+template <typename S>
 __global__ __launch_bounds__(CP_BLOCK) void k_halo_copy(int m, int fs, int nsel, int sel, int K, int col, int pack,
-                                                        double *__restrict__ buf, double *__restrict__ lin) {
+                                                        S *__restrict__ buf, S *__restrict__ lin) {
     const int tot = nsel * m;
     for (int gid = blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot; gid += gridDim.x * CP_BLOCK) {
         const int s = gid / m, i = gid - s * m;
         int f = s;                                                  // CP_SEL_ALL, CP_SEL_X_U, CP_SEL_P_Y12: leading fields
         if (sel == CP_SEL_P_DY) f = K + 4 * (s >> 1) + 1 + 2 * (s & 1);   // Dy u_x, Dy u_y of image s/2
         if (sel == CP_SEL_P_Y2) f = K + s;                                 // all y2 fields
-        double *p = buf + (size_t)f * fs + (size_t)col * m + i;
+        S *p = buf + (size_t)f * fs + (size_t)col * m + i;
         if (pack) lin[gid] = *p; else *p = lin[gid];
     }
 }
@@ -1552,13 +1566,13 @@ __global__ __launch_bounds__(CP_BLOCK) void k_halo_copy(int m, int fs, int nsel,
 //           last owned column (2K fields);
 //   unpack: from_right (a neighbour's to_left) -> halo column nl+1, from_left (a neighbour's to_right) -> halo column 0.
 // A null buffer skips that side (ends of the chain).
-__global__ __launch_bounds__(CP_BLOCK) void k_halo_state(int m, int fs, int K, int nl, int pack, double *__restrict__ xbuf,
-                                                         double *__restrict__ pbuf, double *__restrict__ a7,
-                                                         double *__restrict__ a2) {
+template <typename S>
+__global__ __launch_bounds__(CP_BLOCK) void k_halo_state(int m, int fs, int K, int nl, int pack, S *__restrict__ xbuf,
+                                                         S *__restrict__ pbuf, S *__restrict__ a7, S *__restrict__ a2) {
     const int n7 = a7 ? 7 * K * m : 0, n2 = a2 ? 2 * K * m : 0;
     const int col7 = pack ? 1 : nl + 1, col2 = pack ? nl : 0;
     for (int gid = blockIdx.x * CP_BLOCK + threadIdx.x; gid < n7 + n2; gid += gridDim.x * CP_BLOCK) {
-        double *p, *q;
+        S *p, *q;
         if (gid < n7) {
             const int s = gid / m, i = gid - s * m;
             p = (s < 2 * K ? xbuf + (size_t)s * fs : pbuf + (size_t)(s - 2 * K) * fs) + (size_t)col7 * m + i;
@@ -1586,9 +1600,19 @@ __global__ __launch_bounds__(CP_BLOCK) void k_sumsq_fields(int npix, int m, int 
     block_reduce_store<1, 1>(ss, mm, red, part + (size_t)blockIdx.x * CP_PSTRIDE);
 }
 
+// selections CP_SEL_VEC_*: the same fields as CP_SEL_X_U / CP_SEL_P_DY / CP_SEL_P_Y2, but the buffer holds doubles in
+// every storage mode (vectors of the power iteration in the spare buffers)
+static int mg_base_sel(int sel) {
+    switch (sel) {
+        case CP_SEL_VEC_X_U: return CP_SEL_X_U;
+        case CP_SEL_VEC_P_DY: return CP_SEL_P_DY;
+        case CP_SEL_VEC_P_Y2: return CP_SEL_P_Y2;
+    }
+    return sel;
+}
 static int mg_nsel(const cp_engine *h, int buf, int sel) {
     const bool isx = (buf == CP_BUF_X0 || buf == CP_BUF_X1 || buf == CP_BUF_XTMP);
-    switch (sel) {
+    switch (mg_base_sel(sel)) {
         case CP_SEL_ALL: return isx ? h->nxf : h->npf;
         case CP_SEL_X_U: return isx ? 2 * h->K : -1;
         case CP_SEL_P_Y12: return (isx || h->reg != 0) ? -1 : 5 * h->K;
@@ -1616,20 +1640,28 @@ extern "C" int cp_set_stream(cp_handle h, void *hip_stream) {
     return CP_OK;
 }
 extern "C" int64_t cp_mg_partial_len(void) { return CP_PSTRIDE; }
+// doubles the caller's message buffer needs for one packed halo column (fp32 mode: two floats per double)
 extern "C" int64_t cp_mg_halo_len(cp_handle h, int sel) {
     if (!h || !h->mf) return -1;
-    const int n = (sel == CP_SEL_ALL) ? std::max(h->nxf, h->npf) : mg_nsel(h, sel == CP_SEL_X_U ? CP_BUF_X0 : CP_BUF_P0, sel);
-    return n < 0 ? -1 : (int64_t)n * h->m;
+    const int base = mg_base_sel(sel);
+    const int n = (base == CP_SEL_ALL) ? std::max(h->nxf, h->npf) : mg_nsel(h, base == CP_SEL_X_U ? CP_BUF_X0 : CP_BUF_P0, sel);
+    if (n < 0) return -1;
+    const bool as_float = h->fp32 && base == sel && sel != CP_SEL_ALL;
+    return as_float ? ((int64_t)n * h->m + 1) / 2 : (int64_t)n * h->m;
 }
 static int mg_halo(cp_handle h, int buf, int sel, int col, int pack, double *lin) {
     if (!h || !h->mf || !lin) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg halo exchange needs an mf_nn handle and a buffer");
-    if (h->fp32) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported halo exchange in fp32 mode");
     HIPCHK(hipSetDevice(h->d.device));
     double *b = mg_buf(h, buf);
-    const int nsel = mg_nsel(h, buf, sel);
+    const int nsel = mg_nsel(h, buf, sel), base = mg_base_sel(sel);
     if (!b || nsel <= 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg halo buffer %d / selection %d", buf, sel);
+    if (h->fp32 && sel == CP_SEL_ALL) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported CP_SEL_ALL in fp32 mode");
     const int grid = std::max(1, std::min((nsel * h->m + CP_BLOCK - 1) / CP_BLOCK, 1024));
-    hipLaunchKernelGGL(k_halo_copy, dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->fs, nsel, sel, h->K, col, pack, b, lin);
+    if (h->fp32 && base == sel)
+        hipLaunchKernelGGL((k_halo_copy<float>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->fs, nsel, base, h->K, col, pack,
+                           (float *)b, (float *)lin);
+    else
+        hipLaunchKernelGGL((k_halo_copy<double>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->fs, nsel, base, h->K, col, pack, b, lin);
     HIPCHK(hipGetLastError());
     return CP_OK;
 }
@@ -1642,7 +1674,6 @@ extern "C" int cp_mg_halo_unpack(cp_handle h, int buf, int sel, int side, const 
 
 static int mg_state(cp_handle h, int xbuf, int pbuf, int pack, double *a7, double *a2) {
     if (!h || !h->mf || h->var || h->reg != 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg the state halo needs an NN-TV handle");
-    if (h->fp32) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported halo exchange in fp32 mode");
     HIPCHK(hipSetDevice(h->d.device));
     double *xb = mg_buf(h, xbuf), *pb = mg_buf(h, pbuf);
     const bool xok = (xbuf == CP_BUF_X0 || xbuf == CP_BUF_X1), pok = (pbuf == CP_BUF_P0 || pbuf == CP_BUF_P1);
@@ -1650,7 +1681,11 @@ static int mg_state(cp_handle h, int xbuf, int pbuf, int pack, double *a7, doubl
     if (!a7 && !a2) return CP_OK;
     const int tot = ((a7 ? 7 : 0) + (a2 ? 2 : 0)) * h->K * h->m;
     const int grid = std::max(1, std::min((tot + CP_BLOCK - 1) / CP_BLOCK, 1024));
-    hipLaunchKernelGGL(k_halo_state, dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->fs, h->K, h->nl, pack, xb, pb, a7, a2);
+    if (h->fp32)
+        hipLaunchKernelGGL((k_halo_state<float>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->fs, h->K, h->nl, pack, (float *)xb,
+                           (float *)pb, (float *)a7, (float *)a2);
+    else
+        hipLaunchKernelGGL((k_halo_state<double>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->fs, h->K, h->nl, pack, xb, pb, a7, a2);
     HIPCHK(hipGetLastError());
     return CP_OK;
 }
@@ -1674,13 +1709,16 @@ extern "C" int cp_mg_begin(cp_handle h, double theta, double tau, double sigma, 
     h->profile = true;     // per-launch HIP events of the fused kernel (cp_kernel_time_ms)
     h->it_n = 0;
     h->it_mg = true;
+    // the spare dual buffer may hold a vector of the power iteration (doubles): no stale bit patterns in its halo columns
+    HIPCHK(hipMemsetAsync(h->P[1], 0, sizeof(double) * h->pN, h->stream));
     return mf_begin(h);
 }
 
 extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, int32_t world, double scale,
                            int32_t check_stop, double tol) {
     if (!h || !h->mf || h->var || !dev_buf) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_stage");
-    if (h->reg != 0 && stage <= CP_STAGE_EFUSED) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg fused stages need the NN-TV model");
+    if (h->reg != 0 && stage == CP_STAGE_FUSED) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg CP_STAGE_FUSED needs the NN-TV model");
+    if (h->reg == 0 && stage >= CP_STAGE_CURV_P && stage <= CP_STAGE_CURV_FIN) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg curvature stages need the NN-curvature model");
     HIPCHK(hipSetDevice(h->d.device));
     const bool power = (stage == CP_STAGE_APPLY_A || stage == CP_STAGE_APPLY_AT);
     if (!power && !(h->it_n >= 0 && h->it_mg)) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_stage without cp_mg_begin");
@@ -1717,7 +1755,7 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
         case CP_STAGE_EFUSED: {
             EFusedArgs A;
             A.nblk = world; A.K = h->K; A.n = n; A.check_stop = check_stop; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2;
-            A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot; A.norm21 = P.norm21; A.reg = 0;
+            A.sigma = P.sigma; A.tau = P.tau; A.Ntot = P.Ntot; A.norm21 = P.norm21; A.reg = h->reg;
             A.warm = efused_warm(n);
             if (h->time_all) CPCHK(timer_begin(h, T_EIG));
             hipLaunchKernelGGL(k_mf_efused, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->W[(n + 1) & 1],
@@ -1763,6 +1801,61 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->hist_p, h->hist_d);
             break;
         }
+        case CP_STAGE_ROW0_DUAL: {   // history row 0 (PDO/chambolle_pock.m:89-106): monitors of (x0, y0), nothing is written but the partials
+            launch_mf_dual<1>(h, P, h->X[0], h->X[1], h->P[0], nullptr, h->W[0], 0, 1);
+            int nrows_l = 0;
+            const double *rows_l = staged_partials(h, h->nblk, &nrows_l);
+            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, nrows_l, rows_l, dev_buf);
+            break;
+        }
+        case CP_STAGE_ROW0_EIG: {
+            EigArgs A = eig_args(h, P, 0, 0, 0, 0, 0, tol, 1);
+            A.nblk = world;
+            hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->W[2], h->hist_p, h->hist_d);
+            break;
+        }
+        case CP_STAGE_ROW0_PRIMAL: {
+            launch_mf_primal<1>(h, P, h->X[0], nullptr, h->P[0], h->W[0], 0);
+            int nrows_l = 0;
+            const double *rows_l = staged_partials(h, h->nblk, &nrows_l);
+            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, nrows_l, rows_l, dev_buf);
+            break;
+        }
+        case CP_STAGE_ROW0_FIN: {
+            EigArgs A = eig_args(h, P, 0, 0, 0, 0, 0, tol);
+            A.nblk = world;
+            hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, dev_buf, ctrl, h->hist_p, h->hist_d);
+            break;
+        }
+        case CP_STAGE_CURV_P: {      // NN-curvature in two field passes: k_mf_fused_curv(n) + local reduction -> dev_buf
+            if (n < 1 || n + 2 > h->hist_rows) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg iteration %d beyond the history capacity", n);
+            const int cur = n & 1, prv = (n - 1) & 1, nxt = (n + 1) & 1;
+            CPCHK(timer_begin(h, T_DUAL));
+            if (h->fp32) launch_curv_t<float>(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[nxt], h->W[cur]);
+            else launch_curv_t<double>(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[nxt], h->W[cur]);
+            CPCHK(timer_end(h, T_DUAL));
+            int nrows = 0;
+            const double *rows = fused_partials(h, &nrows);
+            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, nrows, rows, dev_buf);
+            break;
+        }
+        case CP_STAGE_CURV_Y2: {     // k_curv_y2(n) (needs the halo columns of u_n) + local reduction of its scalars -> dev_buf
+            const int cur = n & 1, prv = (n - 1) & 1, nxt = (n + 1) & 1;
+            CPCHK(timer_begin(h, T_PRIMAL));
+            if (h->fp32) launch_curv_y2_t<float>(h, P, h->X[cur], h->X[prv], h->P[cur], h->P[nxt]);
+            else launch_curv_y2_t<double>(h, P, h->X[cur], h->X[prv], h->P[cur], h->P[nxt]);
+            CPCHK(timer_end(h, T_PRIMAL));
+            int nrows = 0;
+            const double *rows = staged_partials(h, h->nblk_y2, &nrows, true);
+            hipLaunchKernelGGL(k_mf_reduce_local, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, nrows, rows, dev_buf);
+            break;
+        }
+        case CP_STAGE_CURV_FIN: {    // k_curv_fin(n) on the gathered rows: F2, F2*, boundary term of the next mean, stop rule
+            CurvFinArgs F;
+            F.nblk = world; F.n = n; F.check_stop = check_stop; F.tol = tol; F.mu2 = P.mu2; F.tau = P.tau; F.Ntot = P.Ntot;
+            hipLaunchKernelGGL(k_curv_fin, dim3(1), dim3(256), 0, h->stream, F, dev_buf, ctrl, h->hist_p, h->hist_d);
+            break;
+        }
         case CP_STAGE_APPLY_A:
             launch_mf_applyA(h, P, h->X[1], scale, h->P[1]);
             break;
@@ -1789,14 +1882,18 @@ extern "C" int cp_mg_end(cp_handle h, int32_t iterations) {
     if (iterations < 0 || iterations + 1 > h->hist_rows)
         CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_end(%d) beyond the %d history rows of cp_mg_begin", iterations, h->hist_rows);
     const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
-    int zero = 0;
+    int hdr[2] = {0, -1}, zero = 0;
+    HIPCHK(hipMemcpyAsync(hdr, h->ctrl, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // the stop rule fired at iteration `iterations` (PDO/chambolle_pock.m:145-153): un-stop so that the canonicalisation runs
+    const bool stopped = hdr[0] != 0 && hdr[1] == iterations;
     HIPCHK(hipMemcpyAsync(h->ctrl, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
     CPCHK(mf_end(h, P, iterations));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->profile = false;
     h->it_n = -1;
     h->it_mg = false;
-    h->last[0] = cp_result{iterations, CP_STOP_MAXITER, iterations + 1, h->hcols};
+    h->last[0] = cp_result{iterations, stopped ? CP_STOP_TOLERANCE : CP_STOP_MAXITER, iterations + 1, h->hcols};
     return CP_OK;
 }
 

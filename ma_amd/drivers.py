@@ -161,9 +161,15 @@ def num_levels(m, n):
 
 
 def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True, single_level=False,
-              fp32=False):
+              fp32=False, slabs=None, slab_min_pixels=1 << 20):
     """fp32=True: CP_FLAG_FP32 storage mode of the engine (fields as float, arithmetic in double); not part of the
-    reference's optPara, results agree with the fp64 mode to about 1e-4 relative."""
+    reference's optPara, results agree with the fp64 mode to about 1e-4 relative.
+
+    slabs=(world, rank[, group]): one process per GPU over torch.distributed (BASELINE config 4). Levels with at least
+    slab_min_pixels pixels run on row slabs (ma_amd.slab_mg.MultiGpuEngine: halo exchange + one small all-gather per
+    half iteration); the coarse levels below that are too small to be worth a message per iteration and run replicated
+    -- every rank solves the whole level on its own GPU, bit for bit the same -- so the hand-over to the first slab level
+    needs no communication either (the slab boundaries double from level to level). Every rank returns the full result."""
     k = len(img)
     img = [normalize(im) for im in img]
     m, n = img[0].shape
@@ -183,13 +189,26 @@ def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_
     for _ in range(levels - 1):
         sizes.insert(0, ((sizes[0][0] + 1) // 2, (sizes[0][1] + 1) // 2))
     engines = []
+    slab_levels, parts = [], {}
+    if slabs is not None and slabs[0] > 1:
+        from . import slab as _slab
+        from .slab_mg import MultiGpuEngine
+        slab_levels = [lv for lv, (ml, nl) in enumerate(sizes) if ml * nl >= slab_min_pixels and nl >= 4 * slabs[0]]
+        if slab_levels:
+            slab_levels = list(range(slab_levels[0], levels))
+            hp = _slab.hierarchical_partitions([sizes[lv][1] for lv in slab_levels], slabs[0], slabs[1])
+            parts = dict(zip(slab_levels, hp))
     try:
-        for (ml, nl) in sizes:
+        for lv, (ml, nl) in enumerate(sizes):
             h_grid = ((omega[1] - omega[0]) / ml, (omega[3] - omega[2]) / nl)          # (:88)
             # the single-level driver's F: SAD weight 1, norm21 with weight mu (NNE/mf_nn_tv_registration_no_ref.m:206-216)
             flags = (E.FLAG_FP32 if fp32 else 0) | (E.FLAG_MFNN_NORM21 if single_level else 0)
-            engines.append(E.Engine(model, ml, nl, k=k, bc=optPara["bc"], h=h_grid, omega=omega, mu=optPara["mu"],
-                                    device=device, flags=flags))
+            if lv in parts:
+                engines.append(MultiGpuEngine(model, ml, nl, k, optPara["bc"], h_grid, omega, optPara["mu"], device, parts[lv],
+                                              group=slabs[2] if len(slabs) > 2 else None, flags=flags))
+            else:
+                engines.append(E.Engine(model, ml, nl, k=k, bc=optPara["bc"], h=h_grid, omega=omega, mu=optPara["mu"],
+                                        device=device, flags=flags))
         engines[-1].set_images(np.concatenate([_vecF(im) for im in img]))
         for lev in range(levels - 1, 0, -1):
             engines[lev].downsample_to(engines[lev - 1])
@@ -213,14 +232,14 @@ def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_
                 else:
                     nu = nu_factor * nu                                                # (:179)
                 eng.set_nu(nu)
-                x0n = normest_x0(3 * k * ml * nl) if normest_x0 is not None else None
+                x0n = normest_x0(3 * k * ml * nl) if (normest_x0 is not None and lev not in parts) else None
                 norm_A_est, n_power = eng.norm_estimate(x0n)                           # (:191-192)
                 tau = math.sqrt(0.99 / norm_A_est ** 2)
                 sigma = math.sqrt(0.99 / norm_A_est ** 2)
                 res = eng.solve(optPara["theta"], tau, sigma, optPara["maxIter"], optPara["tol"])
                 last = (lev == levels - 1) and (o == outerIter - 1)
                 if download_all or last:
-                    x = eng.primal()
+                    x = eng.primal_full() if lev in parts else eng.primal()
                     kmn = k * ml * nl
                     u[lev][o] = x[: 2 * kmn].reshape((ml * nl, 2, k), order="F")
                     L[lev][o] = x[2 * kmn:].reshape((ml, nl, k), order="F")

@@ -129,8 +129,11 @@ EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_im
 
 BUF_X0, BUF_X1, BUF_P0, BUF_P1, BUF_XTMP = 0, 1, 2, 3, 4
 SEL_ALL, SEL_X_U, SEL_P_Y12, SEL_P_DY, SEL_P_Y2 = 0, 1, 2, 3, 4
+SEL_VEC_X_U, SEL_VEC_P_DY, SEL_VEC_P_Y2 = 5, 6, 7
 STAGE_DUAL0, STAGE_EIG0, STAGE_FUSED, STAGE_EFUSED, STAGE_APPLY_A, STAGE_APPLY_AT = 0, 1, 2, 3, 4, 5
 STAGE_SPLIT_DUAL, STAGE_SPLIT_EIG, STAGE_SPLIT_PRIMAL, STAGE_SPLIT_FIN = 6, 7, 8, 9
+STAGE_ROW0_DUAL, STAGE_ROW0_EIG, STAGE_ROW0_PRIMAL, STAGE_ROW0_FIN = 10, 11, 12, 13
+STAGE_CURV_P, STAGE_CURV_Y2, STAGE_CURV_FIN = 14, 15, 16
 
 
 def _chk(rc):

@@ -22,6 +22,26 @@ class Partition:
         if self.nl < 2:
             raise ValueError("slab thinner than 2 columns")
 
+    @classmethod
+    def from_bounds(cls, n, world, rank, j0, j1):
+        p = cls.__new__(cls)
+        p.n, p.world, p.rank, p.j0, p.j1, p.nl = n, world, rank, j0, j1, j1 - j0
+        if p.nl < 2:
+            raise ValueError("slab thinner than 2 columns")
+        return p
+
+
+def hierarchical_partitions(ns, world, rank):
+    """Partitions of a pyramid of column counts ns (coarsest first, each level ceil(n/2) of the next finer one) whose
+    slab boundaries double from level to level: the parent column (j >> 1) of every owned column is owned by the same
+    rank one level below, so prolongation (kron(x, ones(2)), NNE/mf_nn_tv...:113-119) needs no communication."""
+    parts = [Partition(ns[0], world, rank)]
+    bounds = [Partition(ns[0], world, r).j0 for r in range(world)] + [ns[0]]
+    for n in ns[1:]:
+        bounds = [min(2 * b, n) for b in bounds[:-1]] + [n]
+        parts.append(Partition.from_bounds(n, world, rank, bounds[rank], bounds[rank + 1]))
+    return parts
+
 
 class SlabSolver:
     def __init__(self, model, m, n, k, bc, h, omega, mu, device, part, flags=0):
@@ -32,10 +52,8 @@ class SlabSolver:
         if part.world == 1 and os.environ.get("CP_FORCE_SLAB_PATH", "0") != "1":
             self.eng = E.Engine(model, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu, device=device, flags=flags)
         else:
-            if flags:
-                raise ValueError("row slabs run in the fp64 mode only")
             from .slab_mg import MultiGpuEngine
-            self.eng = MultiGpuEngine(model, m, n, k, bc, h, omega, mu, device, part)
+            self.eng = MultiGpuEngine(model, m, n, k, bc, h, omega, mu, device, part, flags=flags)
 
     def set_images(self, imgs_full):
         self.eng.set_images(imgs_full)

@@ -49,3 +49,29 @@ def test_bench_row_slabs_multi_rank(world, reg):
     out = json.loads(lines[0])
     assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["parallelism"] == f"row slabs x{world}"
+
+
+def _run_worker(world, port, **env_extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **{k: str(v) for k, v in env_extra.items()})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0
+
+
+@pytest.mark.parametrize("world,reg,bc,fp32,maxiter,tol,expect_stop,chunk", [
+    (2, "tv", "neumann", 0, 150, 1.0, 1, 32), (3, "tv", "neumann", 1, 40, 1e-3, 0, 32), (3, "tv", "neumann", 0, 150, 1.0, 1, 4),
+    (2, "curvature", "dirichlet", 0, 70, 1e-3, 0, 32), (3, "curvature", "neumann", 1, 40, 1e-3, 0, 32)])
+def test_slab_solve_matches_single_handle(world, reg, bc, fp32, maxiter, tol, expect_stop, chunk):
+    """chambolle_pock on row slabs (MultiGpuEngine.solve): history row 0, stop rule, iteration counts and histories equal
+    cp_solve on one handle; fp64 and fp32 storage; NN-TV (fused kernel) and NN-curvature (two field passes)"""
+    _run_worker(world, 29470 + world + 4 * fp32, SLAB_MODE="solve", SLAB_REG=reg, SLAB_BC=bc, SLAB_FP32=fp32,
+                SLAB_MAXITER=maxiter, SLAB_TOL=tol, SLAB_EXPECT_STOP=expect_stop, SLAB_CHUNK=chunk)
+
+
+@pytest.mark.parametrize("world,reg", [(2, "tv"), (3, "curvature")])
+def test_multilevel_driver_on_slabs(world, reg):
+    """mf_nn_*_registration_no_ref_ml with the two fine levels of three on row slabs (replicated coarse level ->
+    slab level -> slab level: both kinds of prolongation) against the single-GPU driver"""
+    _run_worker(world, 29490 + world, SLAB_MODE="driver", SLAB_REG=reg)

@@ -64,3 +64,26 @@ def test_landmark_utilities():
     img = np.arange(12.0).reshape(3, 4)
     xs = np.array([[0.5, 0.5], [2.5, 3.5], [10.0, 1.0]])
     assert np.allclose(ev._bilinear(img, (1.0, 1.0), xs), [0.0, 11.0, 0.0])   # nodes reproduce pixels, zero outside
+
+
+def test_hierarchical_partitions_keep_parents_local():
+    """slab boundaries double from level to level: the parent column (j >> 1) of every owned column is owned by the same
+    rank one level below (prolongation without communication), slabs cover the columns exactly once, and stay balanced"""
+    from ma_amd.slab import hierarchical_partitions
+    for n_top, levels, world in ((4096, 4, 8), (1000, 3, 3), (517, 2, 4), (136, 2, 2)):
+        ns = [n_top]
+        for _ in range(levels - 1):
+            ns.insert(0, (ns[0] + 1) // 2)
+        parts = [hierarchical_partitions(ns, world, r) for r in range(world)]
+        for lv, n in enumerate(ns):
+            assert parts[0][lv].j0 == 0 and parts[-1][lv].j1 == n
+            for r in range(world):
+                p = parts[r][lv]
+                assert p.n == n and p.nl >= 2
+                if r + 1 < world:
+                    assert p.j1 == parts[r + 1][lv].j0
+                if lv > 0:
+                    c = parts[r][lv - 1]
+                    assert c.j0 <= (p.j0 >> 1) and ((p.j1 - 1) >> 1) < c.j1
+            widths = [parts[r][lv].nl for r in range(world)]
+            assert max(widths) - min(widths) <= 2 ** lv + 1
