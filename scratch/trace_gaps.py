@@ -6,7 +6,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].split("(")[0][:48] for r in rows]
 st = [int(r["Start_Timestamp"]) for r in rows]
 en = [int(r["End_Timestamp"]) for r in rows]
-idx = [i for i, n in enumerate(names) if "k_mf_fused_tv" in n]
+idx = [i for i, n in enumerate(names) if "k_mf_fused_tv" in n or "k_mf_fused_curv" in n]
 idx = idx[len(idx) // 2:]            # second half: steady state
 agg = collections.OrderedDict()
 cnt = 0
