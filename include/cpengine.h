@@ -146,6 +146,25 @@ int cp_set_linearization(cp_handle h, const double *T_u, const double *grad, con
 int cp_evaluate_displacement(int32_t device, const double *img, int32_t m, int32_t n, const double *h, const double *u,
                              const double *omega, int32_t k, int32_t l, double *img_u, double *grad);
 
+/* --- soft nuclear norm and the landscape experiment (NNE/nuclear_norm.m, NNE/test_nuclear_norm_measure.m) -------------
+ * [res1, res2, res3] = nuclear_norm(L, numImg, tau, mu, conjugate_flag)  (NNE/nuclear_norm.m:1-2): L is npix x k, column
+ * major, host memory. conjugate_flag 0: res1 = mu*||L||_*, res2 = 0, prox = U max(S - mu*tau, 0) V' (:43-55);
+ * 1: res1 = 0, res2 = max(max(svd(L/mu)) - 1, 0), prox by Moreau's identity exactly as :78-80 writes it. prox may be NULL
+ * (nargout 2). Singular values come from the eigenvalues of the k x k Gram matrix: values below sqrt(eps)*s_max are noise. */
+int cp_nuclear_norm(int32_t device, const double *L, int64_t npix, int32_t k, double tau, double mu, int32_t conjugate_flag,
+                    double *res1, double *res2, double *prox);
+/* The L-only Chambolle-Pock problems of NNE/test_nuclear_norm_measure.m:122-243, solved by PDO/chambolle_pock.m:75-228:
+ *   version 1: min_L mu*||L||_* + ||L - I||_1       K = identity, F = SAD(., I, 1, sigma), G = nuclear_norm(., k, tau, mu)  (:216-217)
+ *   version 2: min_L delta{||L||_* <= nu} + ||L - I||_1           G = nuclear_norm_constraint(., k, tau, nu)               (:222-226)
+ *   version 3: min_L delta{||B*L||_* <= nu} + ||L - I||_1   K = B, F = nuclear_norm_constraint(., k, tau, nu), G = SAD     (:231-236)
+ * param = mu (1) or nu (2, 3). The script's calls SAD(L, I(:), sigma, c_flag) predate the mu argument of NNE/SAD.m:1; the
+ * engine computes what they mean, SAD(L, I, 1, sigma, c_flag). I, L0, P0 (NULL: zeros, :132-133), L_star, P_star: npix x k
+ * column major, host memory. Histories: caller buffers of (max_iter+1)*5 doubles, filled column major with res->rows rows:
+ * [p, F, G, F_con, G_con] and [q, F*, G*, F*_con, G*_con] (:225-228). Stateless (allocates and frees its device buffers). */
+int cp_nn_measure(int32_t device, int32_t version, const double *I, int64_t npix, int32_t k, double param, const double *L0,
+                  const double *P0, double theta, double tau, double sigma, int32_t max_iter, double tol, double *L_star,
+                  double *P_star, double *primal_history, double *dual_history, cp_result *res);
+
 /* --- mf_nn only --------------------------------------------------------------------------
  * radius nu of the nuclear-norm ball (NNE/mf_nn_tv...:171-180 keeps the schedule on the host) */
 int cp_set_nu(cp_handle h, double nu);

@@ -13,6 +13,7 @@
 #include "cp_mfnn_curv.cuh"
 #include "cp_var.cuh"
 #include "cp_pair.cuh"
+#include "cp_nnl.cuh"
 
 static thread_local std::string g_err;
 
@@ -2008,6 +2009,173 @@ extern "C" int cp_evaluate_displacement(int32_t device, const double *img, int32
     for (double *p : {d_img, d_u, d_T, d_g})
         if (p) hipFree(p);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Soft nuclear norm and the L-only problems of the landscape experiment (cp_nnl.cuh)
+struct NnlWork {
+    size_t npix = 0;
+    int K = 0, grid = 0;
+    double *I = nullptr, *x = nullptr, *xt = nullptr, *xbar = nullptr, *y = nullptr, *part = nullptr, *W = nullptr,
+           *hist_p = nullptr, *hist_d = nullptr;
+    NnlCtrl *ctrl = nullptr;
+    ~NnlWork() {
+        for (void *p : {(void *)I, (void *)x, (void *)xt, (void *)xbar, (void *)y, (void *)part, (void *)W, (void *)hist_p,
+                        (void *)hist_d, (void *)ctrl})
+            if (p) hipFree(p);
+    }
+    int init(size_t npix_, int K_, int hist_rows, bool full) {
+        npix = npix_; K = K_;
+        grid = (int)std::min<size_t>((npix + CP_BLOCK - 1) / CP_BLOCK, 768);
+        const size_t fb = npix * K * sizeof(double);
+        HIPCHK(hipMalloc(&x, fb));
+        HIPCHK(hipMalloc(&xt, fb));
+        if (full) {
+            HIPCHK(hipMalloc(&I, fb));
+            HIPCHK(hipMalloc(&xbar, fb));
+            HIPCHK(hipMalloc(&y, fb));
+            HIPCHK(hipMalloc(&hist_p, sizeof(double) * CP_HCOLS_NNL * hist_rows));
+            HIPCHK(hipMalloc(&hist_d, sizeof(double) * CP_HCOLS_NNL * hist_rows));
+            HIPCHK(hipMemset(hist_p, 0, sizeof(double) * CP_HCOLS_NNL * hist_rows));
+            HIPCHK(hipMemset(hist_d, 0, sizeof(double) * CP_HCOLS_NNL * hist_rows));
+        }
+        HIPCHK(hipMalloc(&part, sizeof(double) * CP_PSTRIDE * grid));
+        HIPCHK(hipMemset(part, 0, sizeof(double) * CP_PSTRIDE * grid));
+        HIPCHK(hipMalloc(&W, sizeof(double) * 256));
+        HIPCHK(hipMalloc(&ctrl, sizeof(NnlCtrl)));
+        HIPCHK(hipMemset(ctrl, 0, sizeof(NnlCtrl)));
+        return CP_OK;
+    }
+    void lin(const double *a, double ca, const double *b, double cb, int useB, double *out, bool gram) {
+        hipLaunchKernelGGL(k_nnl_lin, dim3(grid), dim3(CP_BLOCK), 0, nullptr, ctrl, npix, K, a, ca, b, cb, useB, out,
+                           gram ? part : nullptr);
+    }
+    void spec(int mode, double param) {
+        hipLaunchKernelGGL(k_nnl_spec, dim3(1), dim3(CP_RED_THREADS), 0, nullptr, ctrl, grid, K, mode, param, part, W);
+    }
+    void applyW(const double *in, double *out) {
+        hipLaunchKernelGGL(k_nnl_applyW, dim3(grid), dim3(CP_BLOCK), 0, nullptr, ctrl, npix, K, in, W, out);
+    }
+    void sad(double *v, double s, int conj) {
+        hipLaunchKernelGGL(k_nnl_sad, dim3(grid), dim3(CP_BLOCK), 0, nullptr, ctrl, npix * K, v, I, s, conj);
+    }
+};
+
+static int nnl_check(const void *L, int64_t npix, int32_t k) {
+    if (!L) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg null matrix");
+    if (npix < 1 || k < 1) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg matrix %lld x %d", (long long)npix, k);
+    if (k > CP_KMAX) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported at most %d images (got %d)", CP_KMAX, k);
+    return CP_OK;
+}
+
+extern "C" int cp_nuclear_norm(int32_t device, const double *L, int64_t npix, int32_t k, double tau, double mu,
+                               int32_t conjugate_flag, double *res1, double *res2, double *prox) {
+    CPCHK(nnl_check(L, npix, k));
+    if (!res1 || !res2) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_nuclear_norm needs res1 and res2");
+    if (!(mu > 0.0) || !(tau > 0.0)) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg mu and tau must be positive");
+    HIPCHK(hipSetDevice(device));
+    NnlWork w;
+    CPCHK(w.init((size_t)npix, k, 0, false));
+    const size_t fb = (size_t)npix * k * sizeof(double);
+    HIPCHK(hipMemcpy(w.xt, L, fb, hipMemcpyHostToDevice));
+    NnlCtrl c;
+    if (!conjugate_flag) {
+        w.lin(nullptr, 0.0, w.xt, 1.0, 0, w.x, true);                       // Gram(L)
+        w.spec(NNL_SOFT, mu * tau);                                         // NNE/nuclear_norm.m:43-52
+        if (prox) w.applyW(w.x, w.x);                                       // U max(S - mu tau, 0) V' = L W (:54)
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(&c, w.ctrl, sizeof c, hipMemcpyDeviceToHost));
+        double s = 0.0;
+        for (int i = 0; i < k; ++i) s += c.sv[i];
+        *res1 = mu * s;                                                     // (:47)
+        *res2 = 0.0;
+    } else {
+        w.lin(nullptr, 0.0, w.xt, 1.0 / mu, 0, w.xt, true);                 // L / mu (:63) and its Gram
+        w.spec(NNL_VALUES, 0.0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(&c, w.ctrl, sizeof c, hipMemcpyDeviceToHost));
+        double mx = 0.0;
+        for (int i = 0; i < k; ++i) mx = std::max(mx, c.sv[i]);
+        *res1 = mu * 0.0;                                                   // (:71)
+        *res2 = (mx > 1.0) ? mx - 1.0 : 0.0;                                // (:72-74)
+        if (prox) {   // Moreau (:78-80): (L/mu) - mu tau * prox_{(1/mu)(1/tau)||.||_*}((L/mu) / (mu tau))
+            w.lin(nullptr, 0.0, w.xt, 1.0 / (mu * tau), 0, w.x, true);
+            w.spec(NNL_SOFT, (1.0 / mu) * (1.0 / tau));
+            w.applyW(w.x, w.x);
+            w.lin(w.xt, 1.0, w.x, -(mu * tau), 0, w.x, false);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    if (prox) HIPCHK(hipMemcpy(prox, w.x, fb, hipMemcpyDeviceToHost));
+    return CP_OK;
+}
+
+extern "C" int cp_nn_measure(int32_t device, int32_t version, const double *I, int64_t npix, int32_t k, double param,
+                             const double *L0, const double *P0, double theta, double tau, double sigma,
+                             int32_t max_iter, double tol, double *L_star, double *P_star, double *primal_history,
+                             double *dual_history, cp_result *res) {
+    CPCHK(nnl_check(I, npix, k));
+    if (version < 1 || version > 3) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg version %d (1 soft, 2 hard, 3 mean-free hard)", version);
+    if (version == 3 && k < 2) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg the mean-free problem needs at least 2 images");
+    if (max_iter < 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg max_iter < 0");
+    if (!(tau > 0.0) || !(sigma > 0.0) || !(param > 0.0)) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg tau, sigma and mu|nu must be positive");
+    HIPCHK(hipSetDevice(device));
+    NnlWork w;
+    CPCHK(w.init((size_t)npix, k, max_iter + 1, true));
+    const size_t fb = (size_t)npix * k * sizeof(double), ntot = (size_t)npix * k;
+    HIPCHK(hipMemcpy(w.I, I, fb, hipMemcpyHostToDevice));
+    if (L0) HIPCHK(hipMemcpy(w.x, L0, fb, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(w.x, 0, fb));
+    if (P0) HIPCHK(hipMemcpy(w.y, P0, fb, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(w.y, 0, fb));
+    HIPCHK(hipMemcpy(w.xbar, w.x, fb, hipMemcpyDeviceToDevice));           // PDO/chambolle_pock.m:82-84
+    const int useB = (version == 3) ? 1 : 0;
+    auto row = [&](int r, int use_fsv) {
+        hipLaunchKernelGGL(k_nnl_stats, dim3(w.grid), dim3(CP_BLOCK), 0, nullptr, w.ctrl, w.npix, k, useB, w.x, w.y, w.I, w.part);
+        NnlHistArgs A{w.grid, k, version, r, use_fsv, 1, param, tol};
+        hipLaunchKernelGGL(k_nnl_hist, dim3(1), dim3(CP_RED_THREADS), 0, nullptr, A, w.ctrl, w.part, w.hist_p, w.hist_d);
+    };
+    row(0, 0);
+    for (int i = 1; i <= max_iter; ++i) {
+        // y <- prox_{sigma F*}(y + sigma K xbar)  (:162)
+        w.lin(w.y, 1.0, w.xbar, sigma, useB, w.y, version == 3);
+        if (version == 3) {
+            w.spec(NNL_CONJ_BALL, param * tau);        // nuclear_norm_constraint(., k, tau, nu, true): mu_ = nu * tau (:72)
+            w.applyW(w.y, w.y);
+        } else {
+            w.sad(w.y, sigma, 1);                      // SAD(., I, 1, sigma, true)
+        }
+        // x <- prox_{tau G}(x - tau K' y)  (:165); B is symmetric
+        w.lin(w.x, 1.0, w.y, -tau, useB, w.xt, version != 3);
+        if (version == 3) {
+            hipLaunchKernelGGL(k_nnl_sad, dim3(w.grid), dim3(CP_BLOCK), 0, nullptr, w.ctrl, ntot, w.xt, w.I, sigma, 0);   // SAD(., I, 1, sigma, false)
+        } else {
+            w.spec(version == 1 ? NNL_SOFT : NNL_BALL, version == 1 ? param * tau : param);
+            w.applyW(w.xt, w.xt);
+        }
+        hipLaunchKernelGGL(k_nnl_extrap, dim3(w.grid), dim3(CP_BLOCK), 0, nullptr, w.ctrl, ntot, w.xt, w.x, w.xbar, theta);   // (:179)
+        row(i, 1);
+    }
+    HIPCHK(hipGetLastError());
+    NnlCtrl c;
+    HIPCHK(hipMemcpy(&c, w.ctrl, sizeof c, hipMemcpyDeviceToHost));
+    const int iterations = c.stop ? c.stop_iter : max_iter;
+    const int rows = iterations + 1;
+    if (res) {
+        res->iterations = iterations;
+        res->stop_reason = (c.stop && iterations < max_iter) ? CP_STOP_TOLERANCE : CP_STOP_MAXITER;   // (:137 is tested first)
+        res->rows = rows;
+        res->cols = CP_HCOLS_NNL;
+    }
+    if (L_star) HIPCHK(hipMemcpy(L_star, w.x, fb, hipMemcpyDeviceToHost));
+    if (P_star) HIPCHK(hipMemcpy(P_star, w.y, fb, hipMemcpyDeviceToHost));
+    std::vector<double> tmp((size_t)rows * CP_HCOLS_NNL);
+    for (int which = 0; which < 2; ++which) {
+        double *dst = which ? dual_history : primal_history;
+        if (!dst) continue;
+        HIPCHK(hipMemcpy(tmp.data(), which ? w.hist_d : w.hist_p, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+        for (int cc = 0; cc < CP_HCOLS_NNL; ++cc)
+            for (int r = 0; r < rows; ++r) dst[(size_t)cc * rows + r] = tmp[(size_t)r * CP_HCOLS_NNL + cc];
+    }
+    return CP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

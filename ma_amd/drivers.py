@@ -348,3 +348,84 @@ def var_tv_registration_no_ref(img, optPara, **kw):
     """u = var_tv_registration_no_ref(img, optPara)   (NNE/var_tv_registration_no_ref.m), incl. its swapped SSD prox
     arguments (:173)"""
     return _var_ml(img, optPara, "tv", single_level=True, **kw)[0]
+
+
+# ------------------------------------------------------------------------------------------------
+def nuclear_norm_measure(img, version, answer, numFrames=51, maxIter=200, tol=1e-4, device=0, keep=None):
+    """The landscape experiment NNE/test_nuclear_norm_measure.m:73-251 as a function of the (normalised, downsampled)
+    frames: for numFrames transformations of the second frame (answer 1 translation, 2 rotation, 3 zooming, 4 shearing)
+    the L-only Chambolle-Pock problem of the chosen version (1 soft, 2 hard, 3 mean-free hard nuclear norm) is solved on
+    the device (warp: cp_evaluate_displacement; nu: cp_nuclear_norm; solve: cp_nn_measure). Returns data_term
+    (numFrames x 3 = primal_history(end, 1:3), :243), SSD (:246) and TV (:249) -- the last two are the plot's comparison
+    curves, a few numpy lines on the host. The file heart_mri.mat the script loads is not part of the reference."""
+    numImg = len(img)
+    img = [np.asarray(a, dtype=np.float64).copy() for a in img]
+    m, n = img[0].shape
+    h_img = (1.0 / m, 1.0 / n)                                                        # (:75)
+    t = np.linspace(-1, 1, numFrames)
+    omega = [0.0, 1.0, 0.0, 1.0]
+    h_grid = ((omega[1] - omega[0]) / m, (omega[3] - omega[2]) / n)
+    center = np.array([(omega[3] + omega[2]) / 2, (omega[1] + omega[0]) / 2])         # (:94)
+    xs = omega[0] + h_grid[0] * (np.arange(m) + 0.5)                                  # cell centres (IRE/cell_centered_grid.m)
+    ys = omega[2] + h_grid[1] * (np.arange(n) + 0.5)
+    X = np.stack([np.repeat(xs[:, None], n, axis=1).reshape(-1, order="F"),
+                  np.repeat(ys[None, :], m, axis=0).reshape(-1, order="F")], axis=1)
+    if answer == 1:
+        d = np.array([[1.0, -1.0]])
+        d = d / np.max(np.abs(d))
+    elif answer == 2:
+        c_dist = np.sqrt((X[:, 0] - center[0]) ** 2 + (X[:, 1] - center[1]) ** 2)
+        tmp = 1 - c_dist / 0.375
+        idx = tmp >= 0
+        tmp[idx] = tmp[idx] ** 0.5
+        tmp[~idx] = 0
+        img = [a * tmp.reshape((m, n), order="F") for a in img]                       # (:106-115)
+    theta = 1.0
+    tau = math.sqrt((1 - 1e-4) / 1.0)                                                 # norm_K = 1 (:130,138,153)
+    sigma = tau
+    data_term = np.zeros((numFrames, 3))
+    SSD = np.zeros(numFrames)
+    TV = np.zeros(numFrames)
+    I = np.zeros((m * n, numImg))
+    I[:, 0] = img[0].reshape(-1, order="F")
+    for i in range(numFrames):
+        for j in range(numImg - 1):
+            if answer == 1:
+                u = t[i] * np.ones((m * n, 2)) * d[j]
+            elif answer == 2:
+                alpha = t[i] * math.pi
+                u = (X - center) @ np.array([[math.cos(alpha), math.sin(alpha)], [-math.sin(alpha), math.cos(alpha)]])
+                u = u + center - X
+            elif answer == 3:
+                u = (1 - t[i]) ** 2 * (X - center) + center - X
+            else:
+                u = X - center
+                u[:, 1] = u[:, 1] + t[i] * u[:, 0]
+                u = u + center - X
+            Tu, _ = E.evaluate_displacement(img[j + 1], h_img, u, omega, device=device, want_grad=False)   # (:206-207)
+            I[:, j + 1] = Tu.reshape(-1, order="F")
+        if version == 1:
+            param = math.sqrt(m * n)                                                  # mu (:215)
+        elif version == 2:
+            param = 0.9 * E.nuclear_norm(I, numImg, 1.0, 1.0, device=device)[0]       # nu = 0.9 * sum(svd(I)) (:222-223)
+        else:
+            # nu = 0.9 * sum(svd(B * I)) (:231-233). B*I = I (Id - 11'/k) = (I Q) Q' with the k x (k-1) Helmert basis Q of
+            # the complement of (1,..,1): the non-zero singular values of B*I are those of I*Q, without the exact zero
+            # that a Gram-based routine would turn into sqrt(eps) * s_max
+            Q = np.zeros((numImg, numImg - 1))
+            for c in range(numImg - 1):
+                Q[: c + 1, c] = 1.0
+                Q[c + 1, c] = -(c + 1.0)
+                Q[:, c] /= math.sqrt((c + 1.0) * (c + 2.0))
+            param = 0.9 * E.nuclear_norm(I @ Q, numImg - 1, 1.0, 1.0, device=device)[0]
+        _, _, ph, dh, res = E.nn_measure(version, I, numImg, param, theta, tau, sigma, maxIter, tol, device=device)
+        data_term[i] = ph[-1, 0:3]                                                    # (:243)
+        SSD[i] = np.sum((I[:, 0] - I[:, 1]) ** 2)                                     # (:246)
+        # TV(u) with the 'linear' forward differences of NNE/finite_difference_operator.m:31 (last row u_m - u_{m-1}, unscaled)
+        U = u.reshape((m, n, 2), order="F")
+        dx = np.concatenate([(U[1:] - U[:-1]) / h_grid[0], U[-1:] - U[-2:-1]], axis=0)
+        dy = np.concatenate([(U[:, 1:] - U[:, :-1]) / h_grid[1], U[:, -1:] - U[:, -2:-1]], axis=1)
+        TV[i] = np.sum(np.sqrt(dx[..., 0] ** 2 + dy[..., 0] ** 2 + dx[..., 1] ** 2 + dy[..., 1] ** 2))   # (:249)
+        if keep is not None:
+            keep[i] = dict(I=I.copy(), param=param, ph=ph, dh=dh, iterations=res.iterations, stop_reason=res.stop_reason)
+    return data_term, SSD, TV

@@ -90,6 +90,9 @@ def _load():
         "cp_singular_values_static": [C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp],
         "cp_stream_copy_gbps": [C.c_int32, C.c_int64, C.c_int32, C.c_int32, dp],
         "cp_evaluate_displacement": [C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, C.c_int32, dp, dp],
+        "cp_nuclear_norm": [C.c_int32, dp, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_int32, dp, dp, dp],
+        "cp_nn_measure": [C.c_int32, C.c_int32, dp, C.c_int64, C.c_int32, C.c_double, dp, dp, C.c_double, C.c_double,
+                          C.c_double, C.c_int32, C.c_double, dp, dp, dp, dp, C.POINTER(Result)],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -125,7 +128,8 @@ EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_im
             "cp_downsample", "cp_iterate", "cp_iterate_begin", "cp_iterate_steps", "cp_iterate_end", "cp_sync",
             "cp_kernel_time_ms", "cp_set_stream", "cp_mg_partial_len",
             "cp_mg_halo_len", "cp_mg_halo_pack", "cp_mg_halo_unpack", "cp_mg_state_pack", "cp_mg_state_unpack", "cp_mg_begin", "cp_mg_stage", "cp_mg_end",
-            "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start", "cp_singular_values_static", "cp_stream_copy_gbps", "cp_evaluate_displacement"]
+            "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start", "cp_singular_values_static", "cp_stream_copy_gbps", "cp_evaluate_displacement",
+            "cp_nuclear_norm", "cp_nn_measure"]
 
 BUF_X0, BUF_X1, BUF_P0, BUF_P1, BUF_XTMP = 0, 1, 2, 3, 4
 SEL_ALL, SEL_X_U, SEL_P_Y12, SEL_P_DY, SEL_P_Y2 = 0, 1, 2, 3, 4
@@ -407,3 +411,32 @@ def evaluate_displacement(img, h, u=None, omega=None, s_grid=None, device=0, wan
     g = np.empty(2 * k * l) if want_grad else None
     _chk(lib.cp_evaluate_displacement(int(device), _dptr(imgv), m, n, _dptr(hh), _dptr(uv), _dptr(om), k, l, _dptr(out), _dptr(g)))
     return out.reshape((k, l), order="F"), (None if g is None else g.reshape((k * l, 2), order="F"))
+
+
+def nuclear_norm(L, numImg, tau, mu, conjugate_flag=False, nargout=2, device=0):
+    """[res1, res2, res3] = nuclear_norm(L, numImg, tau, mu, conjugate_flag)  (NNE/nuclear_norm.m:1-2) on the device"""
+    Lv = np.ascontiguousarray(np.asarray(L, dtype=np.float64).reshape(-1, order="F"))
+    npix = Lv.size // int(numImg)
+    r1, r2 = C.c_double(), C.c_double()
+    prox = np.empty_like(Lv) if nargout == 3 else None
+    _chk(lib.cp_nuclear_norm(int(device), _dptr(Lv), npix, int(numImg), float(tau), float(mu), 1 if conjugate_flag else 0,
+                             C.byref(r1), C.byref(r2), _dptr(prox)))
+    return r1.value, r2.value, prox
+
+
+def nn_measure(version, I, numImg, param, theta, tau, sigma, maxIter, tol, L0=None, P0=None, device=0):
+    """[x_star, y_star, primal_history, dual_history] of chambolle_pock(F, G, K, L0, P0, theta, tau, sigma, maxIter, tol) for
+    the L-only problems of NNE/test_nuclear_norm_measure.m:212-242 (version 1 soft / 2 hard / 3 mean-free hard; param =
+    mu or nu); also returns the Result (iterations, stop_reason)."""
+    Iv = np.ascontiguousarray(np.asarray(I, dtype=np.float64).reshape(-1, order="F"))
+    npix = Iv.size // int(numImg)
+    vec = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, order="F"))
+    L0v, P0v = vec(L0), vec(P0)
+    xs, ys = np.empty_like(Iv), np.empty_like(Iv)
+    ph, dh = np.empty((maxIter + 1) * 5), np.empty((maxIter + 1) * 5)
+    res = Result()
+    _chk(lib.cp_nn_measure(int(device), int(version), _dptr(Iv), npix, int(numImg), float(param), _dptr(L0v), _dptr(P0v),
+                           float(theta), float(tau), float(sigma), int(maxIter), float(tol), _dptr(xs), _dptr(ys),
+                           _dptr(ph), _dptr(dh), C.byref(res)))
+    rows = res.rows
+    return xs, ys, ph[: rows * 5].reshape((rows, 5), order="F"), dh[: rows * 5].reshape((rows, 5), order="F"), res

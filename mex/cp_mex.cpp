@@ -162,6 +162,45 @@ void dispatch(const char *cmd, int nlhs, mxArray *plhs[], int nrhs, const mxArra
         if (nlhs > 1) plhs[1] = g;
         return;
     }
+    if (!strcmp(cmd, "nuclear_norm")) {
+        // [res1, res2, res3] = cp_mex('nuclear_norm', L, numImg, tau, mu, conjugate_flag)      NNE/nuclear_norm.m:1-2
+        need(nrhs >= 5, "cp_mex('nuclear_norm', L, numImg, tau, mu, conjugate_flag)");
+        const int k = (int)scalar(prhs[2], "numImg");
+        const size_t tot = mxGetNumberOfElements(prhs[1]);
+        need(k >= 1 && tot % (size_t)k == 0, "cp_mex: numel(L) must be a multiple of numImg");
+        double r1 = 0.0, r2 = 0.0;
+        mxArray *px = (nlhs > 2) ? mxCreateDoubleMatrix(tot, 1, mxREAL) : nullptr;
+        check(cp_nuclear_norm(0, vec_or_null(prhs[1], 0, "L"), (int64_t)(tot / k), k, scalar(prhs[3], "tau"), scalar(prhs[4], "mu"),
+                              nrhs > 5 && scalar(prhs[5], "conjugate_flag") != 0.0, &r1, &r2, px ? mxGetPr(px) : nullptr));
+        plhs[0] = mxCreateDoubleScalar(r1);
+        if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(r2);
+        if (nlhs > 2) plhs[2] = px;
+        return;
+    }
+    if (!strcmp(cmd, "nn_measure")) {
+        // [x_star, y_star, primal_history, dual_history] = cp_mex('nn_measure', version, I, numImg, param, L0, P0, theta,
+        //     tau, sigma, maxIter, tol)                                     NNE/test_nuclear_norm_measure.m:212-242
+        need(nrhs >= 12, "cp_mex('nn_measure', version, I, numImg, param, L0, P0, theta, tau, sigma, maxIter, tol)");
+        const int k = (int)scalar(prhs[3], "numImg");
+        const size_t tot = mxGetNumberOfElements(prhs[2]);
+        need(k >= 1 && tot % (size_t)k == 0, "cp_mex: numel(I) must be a multiple of numImg");
+        const int maxIter = (int)scalar(prhs[10], "maxIter");
+        need(maxIter >= 0, "cp_mex: maxIter >= 0");
+        plhs[0] = mxCreateDoubleMatrix(tot, 1, mxREAL);
+        mxArray *ys = mxCreateDoubleMatrix(tot, 1, mxREAL);
+        mxArray *php = mxCreateDoubleMatrix((mwSize)(maxIter + 1) * 5, 1, mxREAL), *dhp = mxCreateDoubleMatrix((mwSize)(maxIter + 1) * 5, 1, mxREAL);
+        cp_result r;
+        check(cp_nn_measure(0, (int)scalar(prhs[1], "version"), vec_or_null(prhs[2], 0, "I"), (int64_t)(tot / k), k,
+                            scalar(prhs[4], "param"), vec_or_null(prhs[5], tot, "L0"), vec_or_null(prhs[6], tot, "P0"),
+                            scalar(prhs[7], "theta"), scalar(prhs[8], "tau"), scalar(prhs[9], "sigma"), maxIter,
+                            scalar(prhs[11], "tol"), mxGetPr(plhs[0]), mxGetPr(ys), mxGetPr(php), mxGetPr(dhp), &r));
+        if (nlhs > 1) plhs[1] = ys;
+        for (int which = 0; which < 2 && nlhs > 2 + which; ++which) {   // the first rows*5 entries are the rows x 5 matrix
+            plhs[2 + which] = mxCreateDoubleMatrix(r.rows, r.cols, mxREAL);
+            memcpy(mxGetPr(plhs[2 + which]), mxGetPr(which ? dhp : php), sizeof(double) * (size_t)r.rows * r.cols);
+        }
+        return;
+    }
     need(nrhs >= 2, "cp_mex: handle expected");
     cp_handle h = handle_of(prhs[1]);
     const Dims &D = dims_of(h);

@@ -348,3 +348,96 @@ def var_registration_no_ref_ml(img, optPara, reg="tv", normest_x0=normest_start,
                 keep[(lev, o)] = dict(tau=tau, sigma=sigma, norm_est=norm_A_est, n_power=len(e), primal_history=ph,
                                       dual_history=dh, p=p.copy(), x=x.copy(), b=b.copy(), m=m, n=n)
     return u
+
+
+# ------------------------------------------------------------------------------------------------
+def nn_measure_problem(version, I, numImg, m, n, tau, sigma, param):
+    """(F, G, K) of NNE/test_nuclear_norm_measure.m:127-151,212-238 for the image matrix I (mn x numImg). The script's
+    SAD(L, I(:), sigma, c_flag) calls predate the mu argument of NNE/SAD.m:1; they are restated with mu = 1."""
+    import scipy.sparse as sp
+    from . import prox as px
+    Iv = np.asarray(I, dtype=np.float64).reshape(-1, order="F")
+    sad = lambda L, c, nargout: px.SAD(L, Iv, 1.0, sigma, c, nargout)
+    if version == 1:
+        K = sp.identity(m * n * numImg, format="csr")                                                    # (:129)
+        G = lambda L, c, nargout: px.nuclear_norm(L, numImg, tau, param, c, nargout)                     # (:216)
+        return sad, G, K
+    if version == 2:
+        K = sp.identity(m * n * numImg, format="csr")
+        G = lambda L, c, nargout: px.nuclear_norm_constraint(L, numImg, tau, param, c, nargout)          # (:224-225)
+        return sad, G, K
+    K = ops.mean_free_operator(m, n, numImg)                                                             # (:137)
+    F = lambda L, c, nargout: px.nuclear_norm_constraint(L, numImg, tau, param, c, nargout)              # (:234-235)
+    return F, sad, K
+
+
+def nuclear_norm_measure(img, version, answer, numFrames=51, maxIter=200, tol=1e-4, keep=None):
+    """NNE/test_nuclear_norm_measure.m:73-251 as a function of the (already normalised, downsampled) frames img[0..1]:
+    returns data_term (numFrames x 3), SSD, TV."""
+    from .chambolle_pock import chambolle_pock
+    from . import prox as px
+    numImg = len(img)
+    img = [np.asarray(a, dtype=np.float64).copy() for a in img]
+    m, n = img[0].shape
+    h_img = (1.0 / m, 1.0 / n)                                                                           # (:75)
+    t = np.linspace(-1, 1, numFrames)                                                                    # (:84)
+    omega = [0.0, 1.0, 0.0, 1.0]
+    center = np.array([(omega[3] + omega[2]) / 2, (omega[1] + omega[0]) / 2])                            # (:94)
+    xx, yy = ops.cell_centered_grid(omega, (m, n))
+    X = np.stack([xx.reshape(-1, order="F"), yy.reshape(-1, order="F")], axis=1)
+    if answer == 1:
+        d = np.array([[1.0, -1.0]])
+        d = d / np.max(np.abs(d))                                                                        # (:100-101)
+    elif answer == 2:
+        R = 0.375
+        c_dist = np.sqrt((X[:, 0] - center[0]) ** 2 + (X[:, 1] - center[1]) ** 2)
+        tmp = 1 - c_dist / R
+        idx = tmp >= 0
+        tmp[idx] = tmp[idx] ** 0.5
+        tmp[~idx] = 0
+        mask = tmp.reshape((m, n), order="F")
+        img = [a * mask for a in img]                                                                    # (:106-115)
+    h_grid = ((omega[1] - omega[0]) / m, (omega[3] - omega[2]) / n)
+    theta, norm_K = 1.0, 1.0
+    tau = np.sqrt((1 - 1e-4) / norm_K ** 2)                                                              # (:153-154)
+    sigma = tau
+    L0 = np.zeros(m * n * numImg)
+    P0 = np.zeros(m * n * numImg)
+    data_term = np.zeros((numFrames, 3))
+    SSD = np.zeros(numFrames)
+    TV = np.zeros(numFrames)
+    A = ops.finite_difference_operator(m, n, h_grid, 1, "linear")                                        # (:165)
+    I = np.zeros((m * n, numImg))
+    I[:, 0] = img[0].reshape(-1, order="F")
+    for i in range(numFrames):
+        for j in range(numImg - 1):
+            if answer == 1:
+                u = t[i] * np.ones((m * n, 2)) * d[j]                                                    # (:179)
+            elif answer == 2:
+                alpha = t[i] * np.pi
+                u = (X - center) @ np.array([[np.cos(alpha), np.sin(alpha)], [-np.sin(alpha), np.cos(alpha)]])
+                u = u + center - X                                                                       # (:183-187)
+            elif answer == 3:
+                u = (1 - t[i]) ** 2 * (X - center) + center - X                                          # (:191-194)
+            else:
+                u = X - center
+                u[:, 1] = u[:, 1] + t[i] * u[:, 0]
+                u = u + center - X                                                                       # (:198-201)
+            Tu, _ = ops.evaluate_displacement(img[j + 1], h_img, u, omega)                               # (:206-207)
+            I[:, j + 1] = Tu.reshape(-1, order="F")
+        if version == 1:
+            param = np.sqrt(m * n)                                                                       # (:215)
+        elif version == 2:
+            param = 0.9 * np.sum(np.linalg.svd(I, compute_uv=False))                                     # (:222-223)
+        else:
+            Kb = ops.mean_free_operator(m, n, numImg)
+            D = (Kb @ I.reshape(-1, order="F")).reshape((m * n, numImg), order="F")
+            param = 0.9 * np.sum(np.linalg.svd(D, compute_uv=False))                                     # (:231-233)
+        F, G, K = nn_measure_problem(version, I, numImg, m, n, tau, sigma, param)
+        _, _, ph, dh = chambolle_pock(F, G, K, L0, P0, theta, tau, sigma, maxIter, tol)                  # (:241-242)
+        data_term[i] = ph[-1, 0:3]                                                                       # (:243)
+        SSD[i] = np.sum((I[:, 0] - I[:, 1]) ** 2)                                                        # (:246)
+        TV[i] = px.TV_registration(A @ u.reshape(-1, order="F"), None, False, 2)[0]                      # (:249)
+        if keep is not None:
+            keep[i] = dict(I=I.copy(), param=param, ph=ph, dh=dh, tau=tau, sigma=sigma)
+    return data_term, SSD, TV
