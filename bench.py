@@ -36,7 +36,10 @@ def dominant_kernel(reg, k, bc, fp32):
     if reg == "tv":
         lin = "true" if bc == "linear" else "false"
         ka = 16 if k > 12 else (12 if k > 8 else (8 if k > 4 else 4))
-        return f"k_mf_fused_tv<{S}, {lin}, {'true' if k == 16 else 'false'}, {ka}, false>"
+        cw = os.environ.get("CP_TUNE_FUSED_CW", "1") if bc != "linear" else "1"       # lane-tile shape (tuning knob, default 1)
+        if cw != "1":
+            ka = 16
+        return f"k_mf_fused_tv<{S}, {lin}, {'true' if k == 16 else 'false'}, {ka}, false, {cw}>"
     if CURV_SPLIT:
         return f"k_mf_dual<{S}, 0, 1>"
     ka = 16 if k > 12 else (12 if k > 8 else (8 if k > 4 else 4))

@@ -83,6 +83,7 @@ struct cp_engine {
     bool time_all = false;   // CP_TUNE_TIME_ALL=1: HIP events around the small kernels of the fused paths too (each pair of
                              // events costs a few microseconds of stream time; by default only the dominant kernel is timed)
     bool pw_split = false;   // tuning aid (CP_TUNE_PW_SPLIT=1): pairwise models on the split passes instead of k_pw_fused
+    int fused_cw = 1;    // image columns per wavefront of k_mf_fused_tv (template parameter CW; CP_TUNE_FUSED_CW)
     int fused_ka = 1;    // use the K <= 4 / 8 / 12 instantiations of k_mf_fused_tv (CP_TUNE_FUSED_KA=0: always 16)
     int nblk_fused = 0;  // grid of k_mf_fused_tv / k_mf_fused_curv (2 workgroups per CU resident: two LDS tiles per wave)
     int nblk_y2 = 0;     // grid of k_curv_y2
@@ -341,7 +342,9 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         // k_mf_fused_tv: one workgroup task per (part of a column, group of 4 columns), up to 4096 workgroups (512 are
         // resident: 2 per CU), tasks strided by the grid; a multiple of 8 workgroups keeps a part on one XCD. Measured at
         // 4096^2 x 16: 10.4-10.7 ms for grids of 4096, 2048, 1024; 10.8 ms for 512 (persistent).
-        h->nblk_fused = (int)std::min<long long>((fused2_tasks(h->m, h->nl) + 7) / 8 * 8, CP_FUSED_MAXGRID);
+        if (const char *ev = getenv("CP_TUNE_FUSED_CW")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4) h->fused_cw = v; }
+        if (!(mf && !var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (h->d.flags & CP_FLAG_MFNN_NORM21)) h->fused_cw = 1;
+        h->nblk_fused = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         h->curv_fused = mf && !var && h->reg == 1;
         if (const char *ev = getenv("CP_TUNE_CURV_SPLIT")) { if (atoi(ev) != 0) h->curv_fused = false; }
         if (mf) h->nblk_y2 = (int)std::min<long long>((curv_y2_tasks(h->m, h->nl, h->K) + 7) / 8 * 8, CP_FUSED_MAXGRID);
@@ -850,6 +853,8 @@ static void launch_fused_t(cp_engine *h, const MfParams &P, const double *xp, do
     else if (h->K <= 4 && h->fused_ka) kern = lin ? k_mf_fused_tv<S, true, false, 4> : k_mf_fused_tv<S, false, false, 4>;
     else if (h->K <= 8 && h->fused_ka) kern = lin ? k_mf_fused_tv<S, true, false, 8> : k_mf_fused_tv<S, false, false, 8>;
     else if (h->K <= 12 && h->fused_ka) kern = lin ? k_mf_fused_tv<S, true, false, 12> : k_mf_fused_tv<S, false, false, 12>;
+    if (h->fused_cw == 2) kern = (h->K == CP_KMAX) ? k_mf_fused_tv<S, false, true, CP_KMAX, false, 2> : k_mf_fused_tv<S, false, false, CP_KMAX, false, 2>;
+    if (h->fused_cw == 4) kern = (h->K == CP_KMAX) ? k_mf_fused_tv<S, false, true, CP_KMAX, false, 4> : k_mf_fused_tv<S, false, false, CP_KMAX, false, 4>;
     hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
                        (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
 }

@@ -158,20 +158,26 @@ __device__ __forceinline__ void fused_phase1(const MfParams &P, int K, bool vali
 // stays on one XCD (8 parts per column when there are at least 8 segments; gridDim.x % 8 == 0) and the next column
 // group's task -- whose own loads are wave 3's (i, j+1) loads -- is the next workgroup of that XCD.
 struct Fused2Geom { int nseg, parts, steps; };
-__host__ __device__ inline Fused2Geom fused2_geom(int m) {
+__host__ __device__ inline Fused2Geom fused2_geom(int m, int R = 64) {
     Fused2Geom G;
-    G.nseg = (m + 63) >> 6;
+    G.nseg = (m + R - 1) / R;
     G.parts = G.nseg < 8 ? G.nseg : 8;
     G.steps = (G.nseg + G.parts - 1) / G.parts;
     G.parts = (G.nseg + G.steps - 1) / G.steps;   // drop parts that would be empty
     return G;
 }
-__host__ __device__ inline long long fused2_tasks(int m, int nl) { return (long long)fused2_geom(m).parts * ((nl + CP_WAVES - 1) / CP_WAVES); }
+__host__ __device__ inline long long fused2_tasks(int m, int nl, int cw = 1) {
+    return (long long)fused2_geom(m, 64 / cw).parts * ((nl + CP_WAVES * cw - 1) / (CP_WAVES * cw));
+}
 
 // KA = extent of the per-pixel image arrays (4, 8, 12 or 16 >= K): phase 1 loads, multiplies by W and stores KA images, so
 // K = 10 does not pay for 16 (the Gram tiles stay 16 x 16, zero padded). N21: F2 = mu*||.||_{2,1} (NNE/norm21.m, the
 // single-level driver) instead of the pointwise 2x2 nuclear norm.
-template <typename S, bool LINEAR, bool FULLK, int KA = CP_KMAX, bool N21 = false>
+// CW = image columns per wavefront (1, 2 or 4): the 64 lanes form a tile of R = 64/CW rows x CW columns (lane = lc*R + li).
+// With CW > 1 the (i, j+1) neighbour of every column of the tile but the last is the own-pixel result of lane + R (a
+// cross-lane read, bitwise what the recomputation gives); only the last column's lanes recompute it (loads masked to
+// those lanes), and only the last wave's last column reads lines of another workgroup.
+template <typename S, bool LINEAR, bool FULLK, int KA = CP_KMAX, bool N21 = false, int CW = 1>
 __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
                                                               const S *__restrict__ pin, S *__restrict__ pout,
                                                               const S *__restrict__ g, const S *__restrict__ b,
@@ -180,12 +186,16 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S
     constexpr int NWV = CP_WAVES;
     __shared__ double tiles[NWV * 2 * 16 * CP_TS];
     __shared__ double Wl[CP_KMAX * CP_KMAX];
-    __shared__ double carry_all[NWV * 2 * CP_KMAX * 4];   // [wave][step parity][image][ux, uy, ux_old, uy_old] of lane 0
+    constexpr int R = 64 / CW;
+    // [wave][image][tile column][ux, uy, ux_old, uy_old] of the tile's first row: read (by the last row's lanes) before it is
+    // rewritten within a step, in program order of the wave's own LDS instructions
+    __shared__ double carry_all[NWV * CP_KMAX * CW * 4];
     const int stopped = ctrl->stop;
     const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *tileA = tiles + wave * 2 * 16 * CP_TS, *tileB = tileA + 16 * CP_TS;
-    double *carry = carry_all + wave * 2 * CP_KMAX * 4;
+    double *carry = carry_all + wave * CP_KMAX * CW * 4;
+    const int li = lane & (R - 1), lc = lane / R;
     const int K = P.K, m = P.m;
     const size_t fs = (size_t)P.fs;
     const bool linear = LINEAR;
@@ -211,20 +221,25 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S
     maxs[DM_Y1 - CP_NSUM] = 0.0; maxs[DM_S1 - CP_NSUM] = 0.0; maxs[PM_VL - CP_NSUM] = 0.0;
     double4_t acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 
-    const Fused2Geom GM = fused2_geom(m);
-    const int ntasks = GM.parts * ((P.nl + NWV - 1) / NWV);
+    const Fused2Geom GM = fused2_geom(m, R);
+    const int ntasks = GM.parts * ((P.nl + NWV * CW - 1) / (NWV * CW));
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
         const int cg = task / GM.parts, pt = task - cg * GM.parts;
-        const int j = cg * NWV + wave;
-        if (j >= P.nl) continue;                                   // wave-uniform
+        const int jw = (cg * NWV + wave) * CW;                     // first column of the wave's tile
+        if (jw >= P.nl) continue;                                  // wave-uniform
+        const bool colv = jw + lc < P.nl;
+        const int j = min(jw + lc, P.nl - 1);                      // lanes past the last column redo it, nothing is stored
         const int seg_lo = pt * GM.steps, seg_hi = min(seg_lo + GM.steps, GM.nseg) - 1;
         const int jg = P.j_off + j;
         const bool last_j = (jg == P.n_global - 1);
         const int oj = (last_j && LINEAR) ? -1 : 1;
+        // where the (i, j +- 1) result comes from: the lane R further in the tile, or a recomputation
+        const int nbj_lane = lane + oj * R;
+        const bool wantj = LINEAR || !last_j;
+        const bool rcj = wantj && !(lc + oj >= 0 && lc + oj < CW && jw + lc + oj < P.nl);
         for (int sg = seg_hi; sg >= seg_lo; --sg) {
-            const int par = (seg_hi - sg) & 1;                     // carry slot written by this step
-            const int ii = sg * 64 + lane;
-            const bool valid = ii < m;
+            const int ii = sg * R + li;
+            const bool valid = ii < m && colv;
             const int i = min(ii, m - 1);                          // lanes past the end redo the last row, nothing is stored
             const unsigned off = ES * (unsigned)((j + 1) * m + i);
             const bool last_i = (i == m - 1);
@@ -237,16 +252,15 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S
             // where the i-neighbour's own-pixel result comes from: lane +- 1 of this step; for lane 63 the hand-over of the
             // previous step (the segment above); recomputed (lane-masked) only where neither exists
             const int oi = (last_i && LINEAR) ? -1 : 1;
-            const int nb_lane = lane + oi;
+            const int nb_lane = lane + oi, nb_li = li + oi;
             const bool want = valid && (LINEAR || !last_i);          // the neighbour's value is used at all
-            const bool from_carry = want && nb_lane == 64 && sg < seg_hi;
-            const bool recompute = want && (nb_lane < 0 || nb_lane > 63) && !from_carry;
-            const bool any_rc = __any(recompute);                    // wave-uniform: first step of a part / m % 64 == 1 with linear rows
+            const bool from_carry = want && nb_li == R && sg < seg_hi;
+            const bool recompute = want && (nb_li < 0 || nb_li >= R) && !from_carry;
+            const bool any_rc = __any(recompute);                    // wave-uniform: first step of a part / m % R == 1 with linear rows
             const PixOff p0 = {off, off - mb};
             const PixOff pj = {oj > 0 ? off + mb : off - mb, oj > 0 ? off : off - 2u * mb};
             const PixOff pi = {oi > 0 ? off + ES : off - ES, (oi > 0 ? off + ES : off - ES) - mb};
-            const double *cin = carry + (par ^ 1) * CP_KMAX * 4;
-            double *cout_ = carry + par * CP_KMAX * 4;
+            double *cslot = carry + lc * 4;
             const double vmask = valid ? 1.0 : 0.0;
             for (int k = 0; k < K; ++k) {
                 const S *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
@@ -254,6 +268,8 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S
                 const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
                 double ux, uy, uxo_, uyo_, wx, wy, uxj, uyj, oj0, oj1, wd0, wd1;
                 primal_u_at<S, LINEAR>(P, i, jg, p0, fsb, y1k, y2k, gxk, uxk, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
+                // evaluated by every lane (no branch: one basic block, all loads in flight together); with CW > 1 the lanes of
+                // all tile columns but the last touch the lines lane + R reads as its own in the same instruction group
                 primal_u_at<S, LINEAR>(P, i, jg + oj, pj, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
                 const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
                 const double bb = ldo_stream(b + (size_t)k * fs, off);
@@ -263,12 +279,18 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S
                 // bitwise what a recomputation at (i +- 1, j) would give
                 double uxi = __shfl(ux, nb_lane), uyi = __shfl(uy, nb_lane);
                 double oi0 = __shfl(uxo_, nb_lane), oi1 = __shfl(uyo_, nb_lane);
-                if (from_carry) { uxi = cin[4 * k]; uyi = cin[4 * k + 1]; oi0 = cin[4 * k + 2]; oi1 = cin[4 * k + 3]; }
+                if (from_carry) {
+                    const double *cs = cslot + k * CW * 4;
+                    uxi = cs[0]; uyi = cs[1]; oi0 = cs[2]; oi1 = cs[3];
+                }
                 if (any_rc) {
                     if (recompute)
                         primal_u_at<S, LINEAR>(P, i + oi, jg, pi, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
                 }
-                if (lane == 0) { cout_[4 * k] = ux; cout_[4 * k + 1] = uy; cout_[4 * k + 2] = uxo_; cout_[4 * k + 3] = uyo_; }
+                if (li == 0) {
+                    double *cs = cslot + k * CW * 4;
+                    cs[0] = ux; cs[1] = uy; cs[2] = uxo_; cs[3] = uyo_;
+                }
 
                 if (valid) {
                     sto(uxo_k, off, ux);

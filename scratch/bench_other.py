@@ -19,11 +19,17 @@ def run(name, eng, theta, tau, sigma, iters, bytes_iter):
 
 which = sys.argv[1:] or ["c2", "c5", "c4", "var"]
 if "c2" in which:
+    # BASELINE config 2 as worded: Data/rect_1.png -> rect_2.png (fixture copy tests/golden/data_png.npz) upsampled to
+    # 2048^2 with the reference's own resampling facility (evaluate_displacement with s_grid, IRE/evaluate_displacement.m:27-31)
     m = n = 2048
-    fr = synth.dynamic_test_image(m, n, 2).numpy()
+    gd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    png = np.load(os.path.join(gd, "data_png.npz"))
+    nrm = lambda a: (a - a.min()) / (a.max() - a.min())
+    R = E.evaluate_displacement(nrm(png["rect_1"].astype(np.float64)), (1.0, 1.0), s_grid=(m, n), want_grad=False)[0]
+    T = E.evaluate_displacement(nrm(png["rect_2"].astype(np.float64)), (1.0, 1.0), s_grid=(m, n), want_grad=False)[0]
     eng = E.Engine(E.MODEL_TV_L1_REG, m, n, lam=0.7)
-    eng.set_images(fr[1].reshape(-1, order="F"), fr[0].reshape(-1, order="F")); eng.set_primal(np.zeros(2*m*n)); eng.linearize()
-    tau = 5.0; run("C2 TV-L1 2048^2", eng, 1.0, tau, (1 - 1e-4) / (8 * tau), 100, 23 * 8.0 * m * n); eng.close()
+    eng.set_images(T.reshape(-1, order="F"), R.reshape(-1, order="F")); eng.set_primal(np.zeros(2*m*n)); eng.linearize()
+    tau = 5.0; run("C2 TV-L1 rect_1 -> rect_2 upsampled to 2048^2", eng, 1.0, tau, (1 - 1e-4) / (8 * tau), 100, 23 * 8.0 * m * n); eng.close()
 if "c5" in which:
     m = n = 512; B = 256
     fr = synth.dynamic_test_image(m, n, 2).numpy()
