@@ -12,6 +12,7 @@
 #include "cp_mfnn_fused.cuh"
 #include "cp_mfnn_curv.cuh"
 #include "cp_var.cuh"
+#include "cp_var_fused.cuh"
 #include "cp_pair.cuh"
 #include "cp_nnl.cuh"
 
@@ -83,6 +84,8 @@ struct cp_engine {
     bool time_all = false;   // CP_TUNE_TIME_ALL=1: HIP events around the small kernels of the fused paths too (each pair of
                              // events costs a few microseconds of stream time; by default only the dominant kernel is timed)
     bool pw_split = false;   // tuning aid (CP_TUNE_PW_SPLIT=1): pairwise models on the split passes instead of k_pw_fused
+    int var_tiles = 2;        // template parameter NT of k_var_fused_tv (CP_TUNE_VAR_TILES = 2 | 4; 13.5 vs 19.6 ms at 4096^2 x 16)
+    bool var_fused = false;   // variance-TV: one k_var_fused_tv + k_var_efused per iteration (CP_TUNE_VAR_SPLIT=1: split passes)
     int fused_cw = 1;    // image columns per wavefront of k_mf_fused_tv (template parameter CW; CP_TUNE_FUSED_CW)
     int fused_ka = 1;    // use the K <= 4 / 8 / 12 instantiations of k_mf_fused_tv (CP_TUNE_FUSED_KA=0: always 16)
     int nblk_fused = 0;  // grid of k_mf_fused_tv / k_mf_fused_curv (2 workgroups per CU resident: two LDS tiles per wave)
@@ -346,6 +349,9 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (!(mf && !var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (h->d.flags & CP_FLAG_MFNN_NORM21)) h->fused_cw = 1;
         h->nblk_fused = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         h->curv_fused = mf && !var && h->reg == 1;
+        h->var_fused = var && h->reg == 0 && h->nl == h->d.n_global;
+        if (const char *ev = getenv("CP_TUNE_VAR_SPLIT")) { if (atoi(ev) != 0) h->var_fused = false; }
+        if (const char *ev = getenv("CP_TUNE_VAR_TILES")) { if (atoi(ev) == 4) h->var_tiles = 4; }
         if (const char *ev = getenv("CP_TUNE_CURV_SPLIT")) { if (atoi(ev) != 0) h->curv_fused = false; }
         if (mf) h->nblk_y2 = (int)std::min<long long>((curv_y2_tasks(h->m, h->nl, h->K) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         if (const char *ev = getenv("CP_TUNE_FUSED_KA")) h->fused_ka = atoi(ev) != 0;
@@ -1007,6 +1013,43 @@ static int var_iterations(cp_engine *h, const MfParams &P, int n0, int count, in
     HIPCHK(hipGetLastError());
     return CP_OK;
 }
+// ---- fused variance-TV path: dual step 1 alone, then one k_var_fused_tv + k_var_efused per iteration -------------------
+static VarEFusedArgs var_efused_args(const MfParams &P, int n, int start, int check, double tol) {
+    VarEFusedArgs A;
+    A.nblk = 0; A.n = n; A.start = start; A.check_stop = check; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2; A.tau = P.tau;
+    A.Ntot = P.Ntot;
+    return A;
+}
+static int var_fused_start(cp_engine *h, const MfParams &P) {
+    launch_var_dual<0>(h, P, h->X[0], h->X[1], h->P[0], h->P[1], 0, 1);                 // y_1 from xbar_0 = x_0
+    VarEFusedArgs A = var_efused_args(P, 0, 1, 0, 0.0);
+    A.nblk = h->nblk;
+    hipLaunchKernelGGL(k_var_efused, dim3(1), dim3(256), 0, h->stream, A, h->part, (CpCtrl *)h->ctrl, h->hist_p, h->hist_d);
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
+static void launch_var_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn) {
+    const bool lin = (h->d.bc == CP_BC_LINEAR);
+    auto kern = lin ? k_var_fused_tv<true, 4> : k_var_fused_tv<false, 4>;
+    if (h->var_tiles == 2) kern = lin ? k_var_fused_tv<true, 2> : k_var_fused_tv<false, 2>;
+    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, xp, xc, pc, pn, (const double *)h->g,
+                       (const double *)h->b, (const CpCtrl *)h->ctrl, h->part);
+}
+static int var_fused_iterations(cp_engine *h, const MfParams &P, int n0, int count, int check, double tol) {
+    for (int n = n0 + 1; n <= n0 + count; ++n) {
+        const int cur = n & 1, prv = (n - 1) & 1, nxt = (n + 1) & 1;   // x_{n-1} in X[prv], y_n in P[cur]
+        CPCHK(timer_begin(h, T_DUAL));
+        launch_var_fused(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[nxt]);
+        CPCHK(timer_end(h, T_DUAL));
+        VarEFusedArgs A = var_efused_args(P, n, 0, check, tol);
+        if (h->time_all) CPCHK(timer_begin(h, T_EIG));
+        const double *rows = staged_partials(h, h->nblk_fused, &A.nblk, true);
+        hipLaunchKernelGGL(k_var_efused, dim3(1), dim3(256), 0, h->stream, A, rows, (CpCtrl *)h->ctrl, h->hist_p, h->hist_d);
+        if (h->time_all) CPCHK(timer_end(h, T_EIG));
+    }
+    HIPCHK(hipGetLastError());
+    return CP_OK;
+}
 static int var_end(cp_engine *h, const MfParams &P, int iterations) {
     const int fb = iterations & 1;
     hipLaunchKernelGGL(k_var_materialize, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->npf, h->X[fb], h->X[0], h->P[fb],
@@ -1032,9 +1075,12 @@ static int solve_var(cp_engine *h, double theta, double tau, double sigma, int m
                        ctrl, h->hist_p, h->hist_d);
     HIPCHK(hipGetLastError());
     int done = 0, stopped = 0, stop_iter = -1;
+    const bool fused = h->var_fused && maxIter > 0;
+    if (fused) CPCHK(var_fused_start(h, P));
     while (done < maxIter && !stopped) {
         const int cnt = std::min(32, maxIter - done);
-        CPCHK(var_iterations(h, P, done, cnt, 1, tol));
+        if (fused) CPCHK(var_fused_iterations(h, P, done, cnt, 1, tol));
+        else CPCHK(var_iterations(h, P, done, cnt, 1, tol));
         done += cnt;
         int hdr[2];
         HIPCHK(hipMemcpyAsync(hdr, ctrl, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
@@ -1042,7 +1088,7 @@ static int solve_var(cp_engine *h, double theta, double tau, double sigma, int m
         stopped = hdr[0];
         stop_iter = hdr[1];
     }
-    if (!stopped) {   // primal row maxIter trails the last primal pass by one kernel
+    if (!stopped && !fused) {   // primal row maxIter trails the last primal pass by one kernel
         const int cur = maxIter & 1;
         launch_var_dual<1>(h, P, h->X[cur], h->X[cur ^ 1], h->P[cur], nullptr, cur, cur ^ 1);
         hipLaunchKernelGGL(k_var_fin_dual, dim3(1), dim3(256), 0, h->stream, var_fin_args(h, P, maxIter, -1, 0, 0, 0, tol),
@@ -1448,6 +1494,7 @@ extern "C" int cp_iterate_begin(cp_handle h, double theta, double tau, double si
         const MfParams P = mf_params(h, theta, tau, sigma);
         CPCHK(mf_begin(h));
         if ((h->reg == 0 || h->curv_fused) && !h->var) CPCHK(mf_fused_start(h, P, 0.0));
+        if (h->var && h->var_fused) CPCHK(var_fused_start(h, P));
     } else {
         HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(PwCtrl) * h->batch, h->stream));
         HIPCHK(hipMemcpyAsync(h->X[1], h->X[0], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));
@@ -1469,7 +1516,8 @@ extern "C" int cp_iterate_steps(cp_handle h, int32_t iters) {
     HIPCHK(hipEventRecord(t.ev[t.used], h->stream));
     if (h->mf) {
         const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
-        if (h->var) CPCHK(var_iterations(h, P, h->it_n, iters, 0, 0.0));
+        if (h->var && h->var_fused) CPCHK(var_fused_iterations(h, P, h->it_n, iters, 0, 0.0));
+        else if (h->var) CPCHK(var_iterations(h, P, h->it_n, iters, 0, 0.0));
         else if (h->reg == 0 || h->curv_fused) CPCHK(mf_fused_iterations(h, P, h->it_n, iters, 0, 0.0));
         else CPCHK(mf_iterations(h, P, h->it_n, iters, 0, 0.0));
     } else {
@@ -2012,6 +2060,138 @@ extern "C" int cp_evaluate_displacement(int32_t device, const double *img, int32
     };
     const int rc = body();
     for (double *p : {d_img, d_u, d_T, d_g})
+        if (p) hipFree(p);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Evaluation utilities: NNE/landmark_transform.m and NNE/landmark_accuracy.m.
+// k_landmark_transform: one workgroup per landmark. The nearest point of the transformed grid g = p + u (:38-45, MATLAB's
+// min: the first minimum in column-major order) is found by all 256 threads; thread 0 then runs the fixed-point iteration
+// x <- x + (y - F(x)), F(z) = z + [u_x(z), u_y(z)] (bilinear, zero padding, :32-33), at most 100 steps, with the
+// reference's literal termination expression sum(F(x) - LM(i,:).^2) < 1e-12 (:50, :54 -- not a squared distance) and its
+// fallback to the initial guess (:55-57; failed[l] = 1 is the warning).
+__global__ __launch_bounds__(CP_BLOCK) void k_landmark_transform(int m, int n, double om0, double om2, double hx, double hy,
+                                                                 const double *__restrict__ u, const double *__restrict__ LM,
+                                                                 int num_lm, double *__restrict__ out, int *__restrict__ failed) {
+    __shared__ double sd[CP_BLOCK];
+    __shared__ long long sq[CP_BLOCK];
+    const int l = blockIdx.x, tid = threadIdx.x;
+    const double y1 = LM[l], y2 = LM[num_lm + l];
+    const long long tot = (long long)m * n;
+    double best = 1.0e300 * 1.0e300;   // +inf
+    long long bq = tot;
+    for (long long q = tid; q < tot; q += CP_BLOCK) {
+        const int j = (int)(q / m), i = (int)(q - (long long)j * m);
+        const double g1 = __dadd_rn(__dadd_rn(om0, __dmul_rn(hx, (double)i + 0.5)), u[q]);          // IRE/cell_centered_grid.m:21-29
+        const double g2 = __dadd_rn(__dadd_rn(om2, __dmul_rn(hy, (double)j + 0.5)), u[tot + q]);
+        const double e1 = g1 - y1, e2 = g2 - y2;
+        const double d = __dadd_rn(__dmul_rn(e1, e1), __dmul_rn(e2, e2));
+        if (d < best) { best = d; bq = q; }           // q ascends within a thread: the first minimum is kept
+    }
+    sd[tid] = best; sq[tid] = bq;
+    __syncthreads();
+    for (int s = CP_BLOCK / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            const double od = sd[tid + s];
+            const long long oq = sq[tid + s];
+            if (od < sd[tid] || (od == sd[tid] && oq < sq[tid])) { sd[tid] = od; sq[tid] = oq; }
+        }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    const long long q0 = sq[0] < tot ? sq[0] : 0;     // all-NaN input: MATLAB's min returns index 1
+    const int j0 = (int)(q0 / m), i0 = (int)(q0 - (long long)j0 * m);
+    const double p1 = __dadd_rn(om0, __dmul_rn(hx, (double)i0 + 0.5)), p2 = __dadd_rn(om2, __dmul_rn(hy, (double)j0 + 0.5));
+    const double inv1 = 1.0 / hx, inv2 = 1.0 / hy;
+    const double *ux = u, *uy = u + tot;
+    auto F = [&](double z1, double z2, double &f1, double &f2) {
+        double v1, v2, dx, dy;
+        bilinear_tap(ux, m, n, z1, z2, inv1, inv2, v1, dx, dy);
+        bilinear_tap(uy, m, n, z1, z2, inv1, inv2, v2, dx, dy);
+        f1 = z1 + v1; f2 = z2 + v2;
+    };
+    const double ysq1 = y1 * y1, ysq2 = y2 * y2;
+    double x1 = p1, x2 = p2, f1, f2, crit = 0.0;
+    for (int it = 0; it < 100; ++it) {
+        F(x1, x2, f1, f2);
+        x1 = x1 + (y1 - f1);
+        x2 = x2 + (y2 - f2);
+        F(x1, x2, f1, f2);
+        crit = (f1 - ysq1) + (f2 - ysq2);
+        if (crit < 1e-12) break;
+    }
+    const bool fail = !(crit < 1e-12);
+    if (fail) { x1 = p1; x2 = p2; }
+    out[l] = x1; out[num_lm + l] = x2;
+    if (failed) failed[l] = fail ? 1 : 0;
+}
+
+// LM_acc(l) = sum_i ||LM_i(l,:) - mean_i LM_i(l,:)|| / k   (NNE/landmark_accuracy.m:19-27); LM stacked num_lm x 2 x k
+__global__ void k_landmark_accuracy(const double *__restrict__ LM, int num_lm, int k, double *__restrict__ acc) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= num_lm) return;
+    double m1 = 0.0, m2 = 0.0;
+    for (int i = 0; i < k; ++i) { m1 += LM[(size_t)i * 2 * num_lm + l]; m2 += LM[(size_t)i * 2 * num_lm + num_lm + l]; }
+    m1 /= (double)k; m2 /= (double)k;
+    double s = 0.0;
+    for (int i = 0; i < k; ++i) {
+        const double e1 = LM[(size_t)i * 2 * num_lm + l] - m1, e2 = LM[(size_t)i * 2 * num_lm + num_lm + l] - m2;
+        s += sqrt(__dadd_rn(__dmul_rn(e1, e1), __dmul_rn(e2, e2)));
+    }
+    acc[l] = s / (double)k;
+}
+
+extern "C" int cp_landmark_transform(int32_t device, const double *LM, int32_t num_lm, const double *u, int32_t m, int32_t n,
+                                     const double *omega, double *LM_transformed, int32_t *failed) {
+    if (!LM || !u || !omega || !LM_transformed) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_landmark_transform needs LM, u, omega and LM_transformed");
+    if (m < 1 || n < 1 || num_lm < 0) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg field %d x %d, %d landmarks", m, n, num_lm);
+    if (!(omega[1] > omega[0]) || !(omega[3] > omega[2])) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg omega must span a region");
+    if (num_lm == 0) return CP_OK;
+    HIPCHK(hipSetDevice(device));
+    const size_t tot = (size_t)m * n;
+    double *d_u = nullptr, *d_lm = nullptr, *d_out = nullptr;
+    int *d_f = nullptr;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc(&d_u, 2 * tot * sizeof(double)));
+        HIPCHK(hipMalloc(&d_lm, 2 * (size_t)num_lm * sizeof(double)));
+        HIPCHK(hipMalloc(&d_out, 2 * (size_t)num_lm * sizeof(double)));
+        HIPCHK(hipMalloc(&d_f, (size_t)num_lm * sizeof(int)));
+        HIPCHK(hipMemcpy(d_u, u, 2 * tot * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_lm, LM, 2 * (size_t)num_lm * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_landmark_transform, dim3(num_lm), dim3(CP_BLOCK), 0, nullptr, m, n, omega[0], omega[2],
+                           (omega[1] - omega[0]) / m, (omega[3] - omega[2]) / n, d_u, d_lm, num_lm, d_out, d_f);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(LM_transformed, d_out, 2 * (size_t)num_lm * sizeof(double), hipMemcpyDeviceToHost));
+        if (failed) {
+            static_assert(sizeof(int) == sizeof(int32_t), "int32_t flags");
+            HIPCHK(hipMemcpy(failed, d_f, (size_t)num_lm * sizeof(int), hipMemcpyDeviceToHost));
+        }
+        return CP_OK;
+    };
+    const int rc = body();
+    for (void *p : {(void *)d_u, (void *)d_lm, (void *)d_out, (void *)d_f})
+        if (p) hipFree(p);
+    return rc;
+}
+
+extern "C" int cp_landmark_accuracy(int32_t device, const double *LM, int32_t num_lm, int32_t k, double *LM_acc) {
+    if (!LM || !LM_acc || num_lm < 0 || k < 1) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_landmark_accuracy");
+    if (num_lm == 0) return CP_OK;
+    HIPCHK(hipSetDevice(device));
+    double *d_lm = nullptr, *d_acc = nullptr;
+    const size_t len = 2 * (size_t)num_lm * k;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc(&d_lm, len * sizeof(double)));
+        HIPCHK(hipMalloc(&d_acc, (size_t)num_lm * sizeof(double)));
+        HIPCHK(hipMemcpy(d_lm, LM, len * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_landmark_accuracy, dim3((num_lm + 63) / 64), dim3(64), 0, nullptr, d_lm, num_lm, k, d_acc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(LM_acc, d_acc, (size_t)num_lm * sizeof(double), hipMemcpyDeviceToHost));
+        return CP_OK;
+    };
+    const int rc = body();
+    for (double *p : {d_lm, d_acc})
         if (p) hipFree(p);
     return rc;
 }

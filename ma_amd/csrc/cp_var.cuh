@@ -109,6 +109,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
             srb += gx * uxb + gy * uyb;
         }
         const double mrc = src * P.invK, mrb = srb * P.invK;
+        double sy = 0.0, sgx = 0.0, sgy = 0.0, sgxy = 0.0, sgyy = 0.0;   // for the mean of the next un-projected u (cp_var_fused.cuh)
 
         for (int k = 0; k < K; ++k) {
             const double *uxc = xc + (size_t)(2 * k) * fs + e, *uyc = xc + (size_t)(2 * k + 1) * fs + e;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
             const double z = y1n / P.mu1;
             sums[VS_Y1SQ] += z * z;                                   // NNE/SSD.m:66-67
             sums[VS_Y1G] += z * gg;
+            sy += y1n; sgx += gx; sgy += gy; sgxy += gx * y1n; sgyy += gy * y1n;
 
             // ---- y2 ------------------------------------------------------------------------------
             if (REG == 0) {
@@ -224,6 +226,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
             }
             sums[DS_UX] += ux;
             sums[DS_UY] += uy;
+        }
+        if (REG == 0) {   // sum_k grad T_k * (B*y1_new)_k (slots VS_SGX = DS_F2S, VS_SGY = DS_SGY; DS_F2S belongs to curvature)
+            const double my = sy * P.invK;
+            sums[DS_F2S] += sgxy - my * sgx;
+            sums[DS_SGY] += sgyy - my * sgy;
         }
     }
     block_reduce_store<CP_NSUM, CP_NMAX>(sums, maxs, red, part + (size_t)blockIdx.x * CP_PSTRIDE);
