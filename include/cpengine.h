@@ -165,6 +165,19 @@ int cp_nn_measure(int32_t device, int32_t version, const double *I, int64_t npix
                   const double *P0, double theta, double tau, double sigma, int32_t max_iter, double tol, double *L_star,
                   double *P_star, double *primal_history, double *dual_history, cp_result *res);
 
+/* --- evaluation utilities (NNE/landmark_transform.m, NNE/landmark_accuracy.m) ------------------
+ * LM_transformed = landmark_transform(LM, u, omega)  (NNE/landmark_transform.m:1-67): LM is num_lm x 2 (column-major,
+ * host), u the m x n x 2 displacement field (host), omega the image region. For every landmark y the point x with
+ * x + u(x) = y: start at the grid point whose displaced position is closest to y (:38-45, first minimum), at most 100
+ * fixed-point steps x <- x + (y - F(x)) with the reference's literal termination expression (:50,:54) and its fallback
+ * to the initial guess (:55-57). failed (may be NULL): 1 where the reference would print 'Fixed-point iteration
+ * failed!'. One workgroup per landmark; stateless (allocates and frees its device buffers). */
+int cp_landmark_transform(int32_t device, const double *LM, int32_t num_lm, const double *u, int32_t m, int32_t n,
+                          const double *omega, double *LM_transformed, int32_t *failed);
+/* LM_acc = landmark_accuracy(LM)  (NNE/landmark_accuracy.m:1-28): LM = the k cells stacked, num_lm x 2 x k column-major;
+ * LM_acc(l) = mean over the k images of the distance of landmark l to its mean position. */
+int cp_landmark_accuracy(int32_t device, const double *LM, int32_t num_lm, int32_t k, double *LM_acc);
+
 /* --- mf_nn only --------------------------------------------------------------------------
  * radius nu of the nuclear-norm ball (NNE/mf_nn_tv...:171-180 keeps the schedule on the host) */
 int cp_set_nu(cp_handle h, double nu);

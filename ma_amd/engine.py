@@ -90,6 +90,8 @@ def _load():
         "cp_singular_values_static": [C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp],
         "cp_stream_copy_gbps": [C.c_int32, C.c_int64, C.c_int32, C.c_int32, dp],
         "cp_evaluate_displacement": [C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, C.c_int32, dp, dp],
+        "cp_landmark_transform": [C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, C.POINTER(C.c_int32)],
+        "cp_landmark_accuracy": [C.c_int32, dp, C.c_int32, C.c_int32, dp],
         "cp_nuclear_norm": [C.c_int32, dp, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_int32, dp, dp, dp],
         "cp_nn_measure": [C.c_int32, C.c_int32, dp, C.c_int64, C.c_int32, C.c_double, dp, dp, C.c_double, C.c_double,
                           C.c_double, C.c_int32, C.c_double, dp, dp, dp, dp, C.POINTER(Result)],
@@ -129,7 +131,7 @@ EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_im
             "cp_kernel_time_ms", "cp_set_stream", "cp_mg_partial_len",
             "cp_mg_halo_len", "cp_mg_halo_pack", "cp_mg_halo_unpack", "cp_mg_state_pack", "cp_mg_state_unpack", "cp_mg_begin", "cp_mg_stage", "cp_mg_end",
             "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start", "cp_singular_values_static", "cp_stream_copy_gbps", "cp_evaluate_displacement",
-            "cp_nuclear_norm", "cp_nn_measure"]
+            "cp_nuclear_norm", "cp_nn_measure", "cp_landmark_transform", "cp_landmark_accuracy"]
 
 BUF_X0, BUF_X1, BUF_P0, BUF_P1, BUF_XTMP = 0, 1, 2, 3, 4
 SEL_ALL, SEL_X_U, SEL_P_Y12, SEL_P_DY, SEL_P_Y2 = 0, 1, 2, 3, 4
@@ -411,6 +413,31 @@ def evaluate_displacement(img, h, u=None, omega=None, s_grid=None, device=0, wan
     g = np.empty(2 * k * l) if want_grad else None
     _chk(lib.cp_evaluate_displacement(int(device), _dptr(imgv), m, n, _dptr(hh), _dptr(uv), _dptr(om), k, l, _dptr(out), _dptr(g)))
     return out.reshape((k, l), order="F"), (None if g is None else g.reshape((k * l, 2), order="F"))
+
+
+def landmark_transform(LM, u, omega, device=0):
+    """LM_transformed = landmark_transform(LM, u, omega)  (NNE/landmark_transform.m) on the device; also returns the flags
+    of the landmarks whose fixed-point iteration failed (the reference's warning, :55-57)"""
+    LM = np.asarray(LM, dtype=np.float64).reshape(-1, 2)
+    u = np.asarray(u, dtype=np.float64)
+    m, n = u.shape[0], u.shape[1]
+    lmv = np.ascontiguousarray(LM.reshape(-1, order="F"))
+    uv = np.ascontiguousarray(u.reshape(-1, order="F"))
+    om = np.ascontiguousarray(np.asarray(omega, dtype=np.float64).reshape(4))
+    out = np.zeros(2 * LM.shape[0])
+    failed = np.zeros(max(LM.shape[0], 1), dtype=np.int32)
+    _chk(lib.cp_landmark_transform(int(device), _dptr(lmv), LM.shape[0], _dptr(uv), m, n, _dptr(om), _dptr(out),
+                                   failed.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out.reshape((LM.shape[0], 2), order="F"), failed[: LM.shape[0]].astype(bool)
+
+
+def landmark_accuracy(LM, device=0):
+    """LM_acc = landmark_accuracy(LM)  (NNE/landmark_accuracy.m): LM is a list of k (numLM, 2) arrays"""
+    y = np.stack([np.asarray(a, dtype=np.float64).reshape(-1, 2) for a in LM], axis=2)        # numLM x 2 x k
+    acc = np.zeros(y.shape[0])
+    _chk(lib.cp_landmark_accuracy(int(device), _dptr(np.ascontiguousarray(y.reshape(-1, order="F"))), y.shape[0], y.shape[2],
+                                  _dptr(acc)))
+    return acc
 
 
 def nuclear_norm(L, numImg, tau, mu, conjugate_flag=False, nargout=2, device=0):

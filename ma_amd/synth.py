@@ -57,6 +57,26 @@ def dynamic_test_image(m=200, n=200, num_frames=6, device="cpu"):
     return out
 
 
+def dynamic_test_landmarks(m=200, n=200, num_frames=6):
+    """the second output of Data/dynamicTestImage.m: LM (17, 2, num_frames) in the coordinate system
+    omega = [0, m] x [0, n] (:57-81): four corners of the rectangle, five points that move with the ellipse, eight fixed
+    points on the frame. (The file allocates 16 rows, :19, and assigns 17; MATLAB grows the array.)"""
+    LM = np.zeros((17, 2, num_frames))
+    r2 = 0.4 / math.sqrt(2.0)
+    for i in range(1, num_frames + 1):
+        dx = -0.1 * math.sin(math.pi * i / num_frames)
+        dy = 0.1 * math.cos(math.pi * i / num_frames)
+        LM[:, :, i - 1] = [[-0.5, -0.6], [-0.5, -0.2], [0.5, -0.6], [0.5, -0.2],
+                           [-dy, r2 - (dx - 0.25)], [-dy, -r2 - (dx - 0.25)],
+                           [0.4 - dy, 0.25 - dx], [-0.4 - dy, 0.25 - dx], [-dy, 0.25 - dx],
+                           [0.7, 0.7], [0.7, -0.7], [-0.7, 0.7], [-0.7, -0.7],
+                           [0.85, 0.85], [0.85, -0.85], [-0.85, 0.85], [-0.85, -0.85]]
+    LM = LM + 1.0
+    LM[:, 0, :] *= m / 2.0
+    LM[:, 1, :] *= n / 2.0
+    return LM
+
+
 def smooth_displacement(m, n, k, amp=2.0, device="cpu"):
     """Deterministic smooth start displacement u0 ~ (m*n, 2, k) (column-major pixel order):
     u_x = amp*sin(2 pi i/m) cos(2 pi j/n), u_y = amp*cos(2 pi i/m) sin(2 pi j/n), scaled per image."""

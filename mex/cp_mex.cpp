@@ -162,6 +162,31 @@ void dispatch(const char *cmd, int nlhs, mxArray *plhs[], int nrhs, const mxArra
         if (nlhs > 1) plhs[1] = g;
         return;
     }
+    if (!strcmp(cmd, "landmark_transform")) {
+        // [LM_transformed, failed] = cp_mex('landmark_transform', LM, u, omega)      NNE/landmark_transform.m:1
+        need(nrhs >= 4, "cp_mex('landmark_transform', LM, u, omega)");
+        const int num_lm = (int)mxGetM(prhs[1]);
+        need(mxGetN(prhs[1]) == 2, "cp_mex: LM must be numLM x 2");
+        const mwSize *ud = mxGetDimensions(prhs[2]);
+        need(mxGetNumberOfDimensions(prhs[2]) == 3 && ud[2] == 2, "cp_mex: u must be m x n x 2");
+        plhs[0] = mxCreateDoubleMatrix(num_lm, 2, mxREAL);
+        mxArray *fl = mxCreateNumericMatrix(num_lm, 1, mxINT32_CLASS, mxREAL);
+        check(cp_landmark_transform(0, vec_or_null(prhs[1], 0, "LM"), num_lm, vec_or_null(prhs[2], 0, "u"), (int)ud[0], (int)ud[1],
+                                    vec_or_null(prhs[3], 4, "omega"), mxGetPr(plhs[0]), static_cast<int32_t *>(mxGetData(fl))));
+        if (nlhs > 1) plhs[1] = fl;
+        return;
+    }
+    if (!strcmp(cmd, "landmark_accuracy")) {
+        // LM_acc = cp_mex('landmark_accuracy', LM3)  with LM3 = cat(3, LM{:}) (numLM x 2 x k)      NNE/landmark_accuracy.m:1
+        need(nrhs >= 2, "cp_mex('landmark_accuracy', cat(3, LM{:}))");
+        const mwSize nd = mxGetNumberOfDimensions(prhs[1]);
+        const mwSize *ld = mxGetDimensions(prhs[1]);
+        need(ld[1] == 2, "cp_mex: LM must be numLM x 2 x k");
+        const int k = nd > 2 ? (int)ld[2] : 1;
+        plhs[0] = mxCreateDoubleMatrix(ld[0], 1, mxREAL);
+        check(cp_landmark_accuracy(0, vec_or_null(prhs[1], 0, "LM"), (int)ld[0], k, mxGetPr(plhs[0])));
+        return;
+    }
     if (!strcmp(cmd, "nuclear_norm")) {
         // [res1, res2, res3] = cp_mex('nuclear_norm', L, numImg, tau, mu, conjugate_flag)      NNE/nuclear_norm.m:1-2
         need(nrhs >= 5, "cp_mex('nuclear_norm', L, numImg, tau, mu, conjugate_flag)");

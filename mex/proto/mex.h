@@ -15,13 +15,15 @@ extern "C" {
 typedef struct mxArray_tag mxArray;
 typedef size_t mwSize;
 typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
-typedef enum { mxUNKNOWN_CLASS = 0, mxDOUBLE_CLASS = 6, mxUINT64_CLASS = 15 } mxClassID;
+typedef enum { mxUNKNOWN_CLASS = 0, mxDOUBLE_CLASS = 6, mxINT32_CLASS = 12, mxUINT64_CLASS = 15 } mxClassID;
 double *mxGetPr(const mxArray *a);
 void *mxGetData(const mxArray *a);
 double mxGetScalar(const mxArray *a);
 size_t mxGetNumberOfElements(const mxArray *a);
 size_t mxGetM(const mxArray *a);
 size_t mxGetN(const mxArray *a);
+mwSize mxGetNumberOfDimensions(const mxArray *a);
+const mwSize *mxGetDimensions(const mxArray *a);
 bool mxIsDouble(const mxArray *a);
 bool mxIsComplex(const mxArray *a);
 bool mxIsEmpty(const mxArray *a);

@@ -1,6 +1,8 @@
-"""Evaluation utilities of the reference (host side, not on the hot path): landmark transfer through a displacement
-field and the landmark accuracy measure. Same names, arguments and results as
-NNE/landmark_transform.m and NNE/landmark_accuracy.m."""
+"""TEST INFRASTRUCTURE ONLY (the oracle): numpy restatement of the reference's evaluation utilities, landmark transfer
+through a displacement field and the landmark accuracy measure. Same names, arguments and results as
+NNE/landmark_transform.m and NNE/landmark_accuracy.m. The product path is ma_amd/evaluation.py -> cp_landmark_transform /
+cp_landmark_accuracy (HIP); only tests/ may import this module. Parity unpinned: the reference stores no landmark
+vectors."""
 import warnings
 
 import numpy as np

@@ -44,7 +44,7 @@ def test_landmark_utilities():
     """NNE/landmark_transform.m / landmark_accuracy.m: a constant shift is inverted exactly; accuracy of identical
     landmark sets is zero and of a known configuration its closed form"""
     import numpy as np
-    from ma_amd import evaluation as ev
+    from oracle import evaluation as ev
     m, n = 32, 40
     omega = [0.0, float(m), 0.0, float(n)]
     u = np.zeros((m, n, 2))
