@@ -174,6 +174,35 @@ __device__ __forceinline__ double ldo_stream(const S *__restrict__ ubase, unsign
     return (double)__builtin_nontemporal_load(reinterpret_cast<const S *>(reinterpret_cast<const char *>(ubase) + (size_t)off));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Buffer addressing (round 2): a 128-bit resource descriptor in SGPRs (uniform base of ONE field group) + a 32-bit per-lane
+// byte offset (VGPR) + a uniform byte offset (SGPR) + the instruction's cache bits. What ldo()/sto() above only ask for, the
+// buffer instructions guarantee: the compiler turned `uniform base + field*fs + zext(off)` of the fused NN-TV kernel into
+// ~25 loop-invariant 64-bit per-lane offsets (50 VGPRs) plus a 64-bit VALU add per access, and -- at the 256-VGPR limit of
+// two waves per SIMD -- issued the 38 loads of an image in five dependent groups. With descriptors every position is ONE
+// VGPR, and all loads of an image are in flight before the first wait.
+// num_records = 2^32 - 1: the range check (voffset + imm against num_records; soffset is not checked) never fires.
+typedef __amdgpu_buffer_rsrc_t cp_rsrc;
+typedef unsigned int cp_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cp_rsrc mk_rsrc(const void *uniform_base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(uniform_base), 0, -1, 0x00020000);
+}
+template <typename S>
+__device__ __forceinline__ double bld(cp_rsrc r, unsigned voff, unsigned soff = 0u) {
+    if constexpr (sizeof(S) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    else return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+template <typename S>
+__device__ __forceinline__ double bld_stream(cp_rsrc r, unsigned voff, unsigned soff = 0u) {   // nt: read once by the launch
+    if constexpr (sizeof(S) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2));
+    else return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 2));
+}
+template <typename S>
+__device__ __forceinline__ void bst(cp_rsrc r, unsigned voff, unsigned soff, double v) {        // nt streaming store, cf. sto()
+    if constexpr (sizeof(S) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cp_u2, v), r, voff, soff, 2);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r, voff, soff, 2);
+}
+
 // sqrt(x) and 1/sqrt(x) from one v_rsq_f64 and the Goldschmidt / residual steps of the compiler's own f64 sqrt
 // expansion, without its range scaling: arguments here are sums of squares of image-scale quantities. Below 1e-280
 // (in practice: exactly 0) both results are 0.

@@ -26,7 +26,12 @@ static thread_local std::string g_err;
         return (code);                                       \
     } while (0)
 
-#define CP_FUSED_MAXGRID 4096
+// grid cap of the fused field kernels. 4096^2 has 8192 tasks (8 parts x 1024 column groups of 4): ONE task per workgroup,
+// dealt by the dispatcher as slots free up, measured 9.23 ms per launch of k_mf_fused_tv against 9.87-9.90 ms with 4096
+// workgroups walking two tasks each (same box); 16 parts (16384 workgroups of 4 steps) 9.64 ms, 4 parts 9.85 ms.
+#ifndef CP_FUSED_MAXGRID
+#define CP_FUSED_MAXGRID 8192
+#endif
 #define CP_S1_GROUP 64
 
 #define CP_NOT_ITERATING(h) \
@@ -87,6 +92,8 @@ struct cp_engine {
     int var_tiles = 2;        // template parameter NT of k_var_fused_tv (CP_TUNE_VAR_TILES = 2 | 4; 13.5 vs 19.6 ms at 4096^2 x 16)
     bool var_fused = false;   // variance-TV: one k_var_fused_tv + k_var_efused per iteration (CP_TUNE_VAR_SPLIT=1: split passes)
     int fused_cw = 1;    // image columns per wavefront of k_mf_fused_tv (template parameter CW; CP_TUNE_FUSED_CW)
+    int fused_waves = CP_WAVES;   // wavefronts (adjacent columns) per workgroup of k_mf_fused_tv (NWV; CP_TUNE_FUSED_WAVES = 4 | 8)
+    int nblk_tv = 0;              // its grid
     int fused_ka = 1;    // use the K <= 4 / 8 / 12 instantiations of k_mf_fused_tv (CP_TUNE_FUSED_KA=0: always 16)
     int nblk_fused = 0;  // grid of k_mf_fused_tv / k_mf_fused_curv (2 workgroups per CU resident: two LDS tiles per wave)
     int nblk_y2 = 0;     // grid of k_curv_y2
@@ -348,6 +355,11 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (const char *ev = getenv("CP_TUNE_FUSED_CW")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4) h->fused_cw = v; }
         if (!(mf && !var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (h->d.flags & CP_FLAG_MFNN_NORM21)) h->fused_cw = 1;
         h->nblk_fused = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw) + 7) / 8 * 8, CP_FUSED_MAXGRID);
+        if (const char *ev = getenv("CP_TUNE_FUSED_WAVES")) { if (atoi(ev) == 8) h->fused_waves = 8; }
+        if (!(mf && !var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (h->d.flags & CP_FLAG_MFNN_NORM21) || h->fused_cw != 1 ||
+            h->K != CP_KMAX)
+            h->fused_waves = CP_WAVES;
+        h->nblk_tv = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw, h->fused_waves) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         h->curv_fused = mf && !var && h->reg == 1;
         h->var_fused = var && h->reg == 0 && h->nl == h->d.n_global;
         if (const char *ev = getenv("CP_TUNE_VAR_SPLIT")) { if (atoi(ev) != 0) h->var_fused = false; }
@@ -358,6 +370,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (const char *ev = getenv("CP_TUNE_PW_SPLIT")) h->pw_split = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_TIME_ALL")) h->time_all = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_FUSED_GRID")) h->nblk_fused = std::max(8, std::min(h->nblk_fused, atoi(ev) / 8 * 8));
+        h->nblk_tv = std::min(h->nblk_tv, h->nblk_fused);
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
             HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
@@ -819,7 +832,7 @@ static const double *staged_partials(cp_engine *h, int nrows, int *rows, bool sc
     *rows = r2;
     return h->part2;
 }
-static const double *fused_partials(cp_engine *h, int *rows) { return staged_partials(h, h->nblk_fused, rows); }
+static const double *fused_partials(cp_engine *h, int *rows) { return staged_partials(h, (h->reg == 0 && !h->var) ? h->nblk_tv : h->nblk_fused, rows); }
 
 // iterations n = n0+1 .. n0+count of PDO/chambolle_pock.m:156-179 (state parity follows n)
 static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int check, double tol) {
@@ -861,7 +874,8 @@ static void launch_fused_t(cp_engine *h, const MfParams &P, const double *xp, do
     else if (h->K <= 12 && h->fused_ka) kern = lin ? k_mf_fused_tv<S, true, false, 12> : k_mf_fused_tv<S, false, false, 12>;
     if (h->fused_cw == 2) kern = (h->K == CP_KMAX) ? k_mf_fused_tv<S, false, true, CP_KMAX, false, 2> : k_mf_fused_tv<S, false, false, CP_KMAX, false, 2>;
     if (h->fused_cw == 4) kern = (h->K == CP_KMAX) ? k_mf_fused_tv<S, false, true, CP_KMAX, false, 4> : k_mf_fused_tv<S, false, false, CP_KMAX, false, 4>;
-    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
+    if (h->fused_waves == 8) kern = k_mf_fused_tv<S, false, true, CP_KMAX, false, 1, 8>;
+    hipLaunchKernelGGL(kern, dim3(h->nblk_tv), dim3(64 * h->fused_waves), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
                        (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
 }
 static void launch_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,

@@ -70,6 +70,64 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
     wy = -vuy;
 }
 
+// The same evaluation through buffer descriptors (cp_device.cuh: bld): the resources of one image's field groups and the
+// values the own-pixel evaluation loads anyway (so the dual step does not load them a second time).
+struct ImgRsrc { cp_rsrc y1, y2a, y2b, g, u; };     // y1_k | y2_k components 0,1 | components 2,3 | grad T_k (x, y) | u_k (x, y)
+struct PrimalAt { double ux, uy, uxo, uyo, wx, wy, y1, gx, gy, v0, v1, v2, v3; };
+// what one evaluation loads: y1, grad T, the four y2 components at the position and at their adjoint neighbours, u_{n-1}
+struct ImgLoads { double y1, gx, gy, v0, v1, v2, v3, w0m, w1m, w2m, w3m, uxo, uyo, l0, l1, l2, l3; };
+template <typename S, bool LINEAR>
+__device__ __forceinline__ void img_load(const MfParams &P, int i, int jg, unsigned oc, unsigned fsb, const ImgRsrc &R,
+                                         ImgLoads &q) {
+    constexpr unsigned ES = (unsigned)sizeof(S);
+    const int m = P.m;
+    const unsigned oim = oc - ES, ojm = oc - ES * (unsigned)m;        // (i-1, j) and (i, j-1): inside the allocation (halo column)
+    q.y1 = bld<S>(R.y1, oc);
+    q.gx = bld<S>(R.g, oc); q.gy = bld<S>(R.g, oc, fsb);
+    q.v0 = bld<S>(R.y2a, oc); q.v1 = bld<S>(R.y2a, oc, fsb); q.v2 = bld<S>(R.y2b, oc); q.v3 = bld<S>(R.y2b, oc, fsb);
+    q.w0m = bld<S>(R.y2a, oim); q.w2m = bld<S>(R.y2b, oim);                      // Dx components: adjoint along i
+    q.w1m = bld<S>(R.y2a, ojm, fsb); q.w3m = bld<S>(R.y2b, ojm, fsb);            // Dy components: adjoint along j
+    q.uxo = bld<S>(R.u, oc);
+    q.uyo = bld<S>(R.u, oc, fsb);
+    q.l0 = q.l1 = q.l2 = q.l3 = 0.0;
+    if (LINEAR) {
+        const unsigned oli = oc + ES * (unsigned)((m - 1) - i);
+        const int dj = (jg >= P.n_global - 2) ? (P.n_global - 1) - jg : 0;
+        const unsigned olj = oc + ES * (unsigned)(dj * m);
+        q.l0 = bld<S>(R.y2a, oli); q.l2 = bld<S>(R.y2b, oli);
+        q.l1 = bld<S>(R.y2a, olj, fsb); q.l3 = bld<S>(R.y2b, olj, fsb);
+    }
+}
+template <typename S, bool LINEAR>
+__device__ __forceinline__ void img_eval(const MfParams &P, int i, int jg, const ImgLoads &q, double cnx, double cny,
+                                         PrimalAt &r) {
+    const int m = P.m;
+    r.y1 = q.y1; r.gx = q.gx; r.gy = q.gy; r.v0 = q.v0; r.v1 = q.v1; r.v2 = q.v2; r.v3 = q.v3; r.uxo = q.uxo; r.uyo = q.uyo;
+    const double a0 = fwd_diff_adj(q.v0, (i >= 1) ? q.w0m : 0.0, q.l0, i, m, LINEAR, P.inv_h1);
+    const double a1 = fwd_diff_adj(q.v1, (jg >= 1) ? q.w1m : 0.0, q.l1, jg, P.n_global, LINEAR, P.inv_h2);
+    const double a2 = fwd_diff_adj(q.v2, (i >= 1) ? q.w2m : 0.0, q.l2, i, m, LINEAR, P.inv_h1);
+    const double a3 = fwd_diff_adj(q.v3, (jg >= 1) ? q.w3m : 0.0, q.l3, jg, P.n_global, LINEAR, P.inv_h2);
+    const double vux = -q.gx * q.y1 + (a0 + a1);
+    const double vuy = -q.gy * q.y1 + (a2 + a3);
+    r.ux = rnd<S>((q.uxo - P.tau * vux) - cnx);  // NNE/mean_zero_indicator.m:50 (the stored value is the iterate)
+    r.uy = rnd<S>((q.uyo - P.tau * vuy) - cny);  // :53
+    r.wx = -vux;
+    r.wy = -vuy;
+}
+template <typename S, bool LINEAR>
+__device__ __forceinline__ void primal_u_at_b(const MfParams &P, int i, int jg, unsigned oc, unsigned fsb, const ImgRsrc &R,
+                                              double cnx, double cny, PrimalAt &r) {
+    ImgLoads q;
+    img_load<S, LINEAR>(P, i, jg, oc, fsb, R, q);
+    img_eval<S, LINEAR>(P, i, jg, q, cnx, cny, r);
+}
+template <typename S>
+__device__ __forceinline__ ImgRsrc img_rsrc(const S *pin, const S *g, const S *xo, int K, int k, size_t fs) {
+    const S *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
+    return ImgRsrc{mk_rsrc(pin + (size_t)k * fs), mk_rsrc(y2k), mk_rsrc(y2k + 2 * fs), mk_rsrc(g + 2 * (size_t)k * fs),
+                   mk_rsrc(xo + 2 * (size_t)k * fs)};
+}
+
 // Phase 1 of the fused passes (NN-TV and NN-curvature): everything that couples the K images of one pixel.
 //   y3_n = y3~_n * W_n (lazy nuclear-norm prox), (A'y)_L = y1_n + B*y3_n, L_n = L_{n-1} - tau*(A'y)_L (zero_function prox),
 //   Lbar = L_n + theta*(L_n - L_{n-1}), y3~_{n+1} = y3_n + sigma*B*Lbar; stores L_n and y3~_{n+1}; accumulates the Gram
@@ -157,17 +215,20 @@ __device__ __forceinline__ void fused_phase1(const MfParams &P, int K, bool vali
 // waves 0..2 are the lines the next wave streams at the same moment. Tasks (part, column group) are dealt so that a part
 // stays on one XCD (8 parts per column when there are at least 8 segments; gridDim.x % 8 == 0) and the next column
 // group's task -- whose own loads are wave 3's (i, j+1) loads -- is the next workgroup of that XCD.
+#ifndef CP_FUSED_PARTS
+#define CP_FUSED_PARTS 8
+#endif
 struct Fused2Geom { int nseg, parts, steps; };
 __host__ __device__ inline Fused2Geom fused2_geom(int m, int R = 64) {
     Fused2Geom G;
     G.nseg = (m + R - 1) / R;
-    G.parts = G.nseg < 8 ? G.nseg : 8;
+    G.parts = G.nseg < CP_FUSED_PARTS ? G.nseg : CP_FUSED_PARTS;
     G.steps = (G.nseg + G.parts - 1) / G.parts;
     G.parts = (G.nseg + G.steps - 1) / G.steps;   // drop parts that would be empty
     return G;
 }
-__host__ __device__ inline long long fused2_tasks(int m, int nl, int cw = 1) {
-    return (long long)fused2_geom(m, 64 / cw).parts * ((nl + CP_WAVES * cw - 1) / (CP_WAVES * cw));
+__host__ __device__ inline long long fused2_tasks(int m, int nl, int cw = 1, int waves = CP_WAVES) {
+    return (long long)fused2_geom(m, 64 / cw).parts * ((nl + waves * cw - 1) / (waves * cw));
 }
 
 // KA = extent of the per-pixel image arrays (4, 8, 12 or 16 >= K): phase 1 loads, multiplies by W and stores KA images, so
@@ -177,13 +238,15 @@ __host__ __device__ inline long long fused2_tasks(int m, int nl, int cw = 1) {
 // With CW > 1 the (i, j+1) neighbour of every column of the tile but the last is the own-pixel result of lane + R (a
 // cross-lane read, bitwise what the recomputation gives); only the last column's lanes recompute it (loads masked to
 // those lanes), and only the last wave's last column reads lines of another workgroup.
-template <typename S, bool LINEAR, bool FULLK, int KA = CP_KMAX, bool N21 = false, int CW = 1>
-__global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
+// NWV = wavefronts (= adjacent image columns) per workgroup: 4 (two workgroups per CU) or 8 (one workgroup per CU, the same
+// two waves per SIMD): only the last wave's (i, j+1) lines and the first wave's (i, j-1) lines belong to another workgroup,
+// so 8 columns halve the cross-workgroup re-reads.
+template <typename S, bool LINEAR, bool FULLK, int KA = CP_KMAX, bool N21 = false, int CW = 1, int NWV = CP_WAVES>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
                                                               const S *__restrict__ pin, S *__restrict__ pout,
                                                               const S *__restrict__ g, const S *__restrict__ b,
                                                               const double *__restrict__ W,
                                                               const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
-    constexpr int NWV = CP_WAVES;
     __shared__ double tiles[NWV * 2 * 16 * CP_TS];
     __shared__ double Wl[CP_KMAX * CP_KMAX];
     constexpr int R = 64 / CW;
@@ -257,25 +320,66 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S
             const bool from_carry = want && nb_li == R && sg < seg_hi;
             const bool recompute = want && (nb_li < 0 || nb_li >= R) && !from_carry;
             const bool any_rc = __any(recompute);                    // wave-uniform: first step of a part / m % R == 1 with linear rows
-            const PixOff p0 = {off, off - mb};
-            const PixOff pj = {oj > 0 ? off + mb : off - mb, oj > 0 ? off : off - 2u * mb};
-            const PixOff pi = {oi > 0 ? off + ES : off - ES, (oi > 0 ? off + ES : off - ES) - mb};
+            const unsigned offj = oj > 0 ? off + mb : off - mb;            // (i, j +- 1)
+            const unsigned offi = oi > 0 ? off + ES : off - ES;            // (i +- 1, j), only where it is recomputed
             double *cslot = carry + lc * 4;
             const double vmask = valid ? 1.0 : 0.0;
+#ifdef CP_EXP_NO_STORES   // timing experiment only: every store of phase 2 dropped by the range check
+            const unsigned off_st = 0xFFFFFFFFu;
+#else
+            const unsigned off_st = valid ? off : 0xFFFFFFFFu;
+#endif
+#ifndef CP_FUSED_PIPE
+#define CP_FUSED_PIPE 0
+#endif
+            // Software pipeline over the images: the loads of image k+1 (own pixel, (i, j+1), b) are issued before the
+            // arithmetic of image k, so a wave's round trip to memory overlaps its own arithmetic and not only the other
+            // wave's of its SIMD. (The kernel is bound by the latency chain of its slowest wave -- the last wave of a
+            // workgroup, whose (i, j+1) lines nobody else streams -- not by bytes: removing the (i, j+1) loads of the other
+            // three waves changed nothing.)
+            ImgLoads q0, qj;
+            double qb;
+            if (CP_FUSED_PIPE) {
+                const ImgRsrc R0 = img_rsrc<S>(pin, g, xo, K, 0, fs);
+                img_load<S, LINEAR>(P, i, jg, off, fsb, R0, q0);
+                img_load<S, LINEAR>(P, i, jg + oj, offj, fsb, R0, qj);
+                qb = bld_stream<S>(mk_rsrc(b), off);
+            }
             for (int k = 0; k < K; ++k) {
-                const S *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
-                const S *gxk = g + 2 * (size_t)k * fs, *uxk = xo + 2 * (size_t)k * fs;
+                // descriptors of this image's field groups (uniform: SALU); every position is one 32-bit VGPR offset
+                S *o2k = pout + ((size_t)K + 4 * (size_t)k) * fs;
+                const ImgRsrc R = img_rsrc<S>(pin, g, xo, K, k, fs);
+                const cp_rsrc Run = mk_rsrc(xn + 2 * (size_t)k * fs),
+                              Ro1 = mk_rsrc(pout + (size_t)k * fs), Ro2a = mk_rsrc(o2k), Ro2b = mk_rsrc(o2k + 2 * fs);
                 const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
-                double ux, uy, uxo_, uyo_, wx, wy, uxj, uyj, oj0, oj1, wd0, wd1;
-                primal_u_at<S, LINEAR>(P, i, jg, p0, fsb, y1k, y2k, gxk, uxk, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
-                // evaluated by every lane (no branch: one basic block, all loads in flight together); with CW > 1 the lanes of
-                // all tile columns but the last touch the lines lane + R reads as its own in the same instruction group
-                primal_u_at<S, LINEAR>(P, i, jg + oj, pj, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
-                const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
-                const double bb = ldo_stream(b + (size_t)k * fs, off);
-                const double y1 = ldo(y1k, off);
-                const double v0 = ldo(y2k, off), v1 = ldo(y2k + fs, off), v2 = ldo(y2k + 2 * fs, off), v3 = ldo(y2k + 3 * fs, off);
-                S *uxo_k = xn + 2 * (size_t)k * fs;
+                PrimalAt r0, rj;
+                double bb;
+                if (CP_FUSED_PIPE) {
+                    const ImgLoads c0 = q0, cj = qj;
+                    bb = qb;
+                    if (k + 1 < K) {                                   // uniform
+                        const ImgRsrc Rn = img_rsrc<S>(pin, g, xo, K, k + 1, fs);
+                        img_load<S, LINEAR>(P, i, jg, off, fsb, Rn, q0);
+                        img_load<S, LINEAR>(P, i, jg + oj, offj, fsb, Rn, qj);
+                        qb = bld_stream<S>(mk_rsrc(b + (size_t)(k + 1) * fs), off);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                 // the prefetch is issued before image k's arithmetic
+                    img_eval<S, LINEAR>(P, i, jg, c0, cnx, cny, r0);
+                    img_eval<S, LINEAR>(P, i, jg + oj, cj, cnx, cny, rj);
+                } else {
+                    primal_u_at_b<S, LINEAR>(P, i, jg, off, fsb, R, cnx, cny, r0);
+                    // evaluated by every lane (no branch: one basic block, all loads in flight together); with CW > 1 the lanes
+                    // of all tile columns but the last touch the lines lane + R reads as its own in the same instruction group
+#ifdef CP_EXP_NO_NB        // timing experiment only (wrong results): no (i, j+1) evaluation at all
+                    rj = r0;
+#else
+                    primal_u_at_b<S, LINEAR>(P, i, jg + oj, offj, fsb, R, cnx, cny, rj);
+#endif
+                    bb = bld_stream<S>(mk_rsrc(b + (size_t)k * fs), off);
+                }
+                const double ux = r0.ux, uy = r0.uy, uxo_ = r0.uxo, uyo_ = r0.uyo, wx = r0.wx, wy = r0.wy;
+                const double gx = r0.gx, gy = r0.gy, y1 = r0.y1, v0 = r0.v0, v1 = r0.v1, v2 = r0.v2, v3 = r0.v3;
+                const double uxj = rj.ux, uyj = rj.uy, oj0 = rj.uxo, oj1 = rj.uyo;
                 // bitwise what a recomputation at (i +- 1, j) would give
                 double uxi = __shfl(ux, nb_lane), uyi = __shfl(uy, nb_lane);
                 double oi0 = __shfl(uxo_, nb_lane), oi1 = __shfl(uyo_, nb_lane);
@@ -284,22 +388,27 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S
                     uxi = cs[0]; uyi = cs[1]; oi0 = cs[2]; oi1 = cs[3];
                 }
                 if (any_rc) {
-                    if (recompute)
-                        primal_u_at<S, LINEAR>(P, i + oi, jg, pi, fsb, y1k, y2k, gxk, uxk, cnx, cny, uxi, uyi, oi0, oi1, wd0, wd1);
+                    if (recompute) {
+                        PrimalAt ri;
+                        primal_u_at_b<S, LINEAR>(P, i + oi, jg, offi, fsb, R, cnx, cny, ri);
+                        uxi = ri.ux; uyi = ri.uy; oi0 = ri.uxo; oi1 = ri.uyo;
+                    }
                 }
                 if (li == 0) {
                     double *cs = cslot + k * CW * 4;
                     cs[0] = ux; cs[1] = uy; cs[2] = uxo_; cs[3] = uyo_;
                 }
 
-                if (valid) {
-                    sto(uxo_k, off, ux);
-                    sto(uxo_k + fs, off, uy);
-                    maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], wx);
-                    maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], -wx);
-                    maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], wy);
-                    maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], -wy);
-                }
+                // stores are unconditional instructions: lanes past the end of the column / the slab carry an offset beyond
+                // the descriptor's range (off_st = 2^32 - 1) and the buffer range check drops them. A branch around the
+                // stores would make the number of memory operations in flight unknown to the compiler, which then waits for
+                // ALL of them (vmcnt(0)) -- the stores of image k included -- before it touches the prefetched image k+1.
+                bst<S>(Run, off_st, 0u, ux);
+                bst<S>(Run, off_st, fsb, uy);
+                maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], valid ? wx : -1.0e300);
+                maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], valid ? -wx : -1.0e300);
+                maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], valid ? wy : -1.0e300);
+                maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], valid ? -wy : -1.0e300);
                 sums[PS_WX] += vmask * wx;
                 const double uxb = ux + theta * (ux - uxo_), uyb = uy + theta * (uy - uyo_);
                 const double uxbi = uxi + theta * (uxi - oi0), uybi = uyi + theta * (uyi - oi1);
@@ -337,13 +446,10 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_tv(MfParams P, const S
                     proj_spectral_2x2(t0, t1, t2, t3, P.mu2, n0, n1, n2, n3, s1v);
                 }
                 if (sizeof(S) == 4) { n0 = rnd<S>(n0); n1 = rnd<S>(n1); n2 = rnd<S>(n2); n3 = rnd<S>(n3); }
-                if (valid) {
-                    S *o1 = pout + (size_t)k * fs, *o2 = pout + ((size_t)K + 4 * (size_t)k) * fs;
-                    sto(o1, off, y1n);
-                    sto(o2, off, n0); sto(o2 + fs, off, n1); sto(o2 + 2 * fs, off, n2); sto(o2 + 3 * fs, off, n3);
-                    maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], fabs(y1n));
-                    maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], s1v);
-                }
+                bst<S>(Ro1, off_st, 0u, y1n);
+                bst<S>(Ro2a, off_st, 0u, n0); bst<S>(Ro2a, off_st, fsb, n1); bst<S>(Ro2b, off_st, 0u, n2); bst<S>(Ro2b, off_st, fsb, n3);
+                maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], valid ? fabs(y1n) : 0.0);
+                maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], valid ? s1v : 0.0);
                 sums[DS_UX] += vmask * ux;
                 sums[DS_UY] += vmask * uy;
             }
