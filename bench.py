@@ -30,7 +30,7 @@ CURV_SPLIT = os.environ.get("CP_TUNE_CURV_SPLIT", "0") not in ("", "0")
 ELEMS_DOM = {"tv": 37, "curvature": 17 if CURV_SPLIT else 23}
 
 
-def dominant_kernel(reg, k, bc, fp32):
+def dominant_kernel(reg, k, bc, fp32, m=4096, nl=4096):
     """name of the dominant kernel as rocprofv3 prints it, derived from what cp_engine.hip launches for this configuration"""
     S = "float" if fp32 else "double"
     if reg == "tv":
@@ -39,7 +39,10 @@ def dominant_kernel(reg, k, bc, fp32):
         cw = os.environ.get("CP_TUNE_FUSED_CW", "1") if bc != "linear" else "1"       # lane-tile shape (tuning knob, default 1)
         if cw != "1":
             ka = 16
-        return f"k_mf_fused_tv<{S}, {lin}, {'true' if k == 16 else 'false'}, {ka}, false, {cw}>"
+        waves = os.environ.get("CP_TUNE_FUSED_WAVES", "8")                             # columns per workgroup (tuning knob)
+        big = ((m + 63) // 64 if m < 512 else 8) * ((nl + 7) // 8) >= 256                # cp_create: every CU gets a workgroup
+        waves = "8" if (waves != "4" and k == 16 and bc != "linear" and cw == "1" and big and not fp32) else "4"
+        return f"k_mf_fused_tv<{S}, {lin}, {'true' if k == 16 else 'false'}, {ka}, false, {cw}, {waves}>"
     if CURV_SPLIT:
         return f"k_mf_dual<{S}, 0, 1>"
     ka = 16 if k > 12 else (12 if k > 8 else (8 if k > 4 else 4))
@@ -326,7 +329,7 @@ def main():
     times = solver.kernel_times()
 
     if rank == 0:
-        kernel = dominant_kernel(reg, k, bc, args.fp32)
+        kernel = dominant_kernel(reg, k, bc, args.fp32, m, part.nl)
         traffic, traffic_src = committed_traffic(kernel, m, part.nl, k) if world == 1 else (None, None)
         kmn_total = float(k) * m * n
         its = args.steps / dt

@@ -192,6 +192,18 @@ __device__ __forceinline__ double bld(cp_rsrc r, unsigned voff, unsigned soff = 
     if constexpr (sizeof(S) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
     else return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// the stored value as it is (fp32 mode: the conversion to double is left to the consumer, so that a group of loads has
+// distinct one-register destinations and none of them waits for the one before)
+template <typename S>
+__device__ __forceinline__ S bld_raw(cp_rsrc r, unsigned voff, unsigned soff = 0u) {
+    if constexpr (sizeof(S) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+template <typename S>
+__device__ __forceinline__ S bld_raw_stream(cp_rsrc r, unsigned voff, unsigned soff = 0u) {
+    if constexpr (sizeof(S) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2));
+    else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 2));
+}
 template <typename S>
 __device__ __forceinline__ double bld_stream(cp_rsrc r, unsigned voff, unsigned soff = 0u) {   // nt: read once by the launch
     if constexpr (sizeof(S) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2));

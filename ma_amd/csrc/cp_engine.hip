@@ -355,9 +355,12 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (const char *ev = getenv("CP_TUNE_FUSED_CW")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4) h->fused_cw = v; }
         if (!(mf && !var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (h->d.flags & CP_FLAG_MFNN_NORM21)) h->fused_cw = 1;
         h->nblk_fused = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw) + 7) / 8 * 8, CP_FUSED_MAXGRID);
-        if (const char *ev = getenv("CP_TUNE_FUSED_WAVES")) { if (atoi(ev) == 8) h->fused_waves = 8; }
+        // 8 adjacent columns per workgroup with the LDS hand-over between neighbouring waves (cp_mfnn_fused.cuh) where that
+        // instantiation exists (K = 16, neumann / dirichlet rows) and the problem still gives every CU a workgroup
+        h->fused_waves = 8;
+        if (const char *ev = getenv("CP_TUNE_FUSED_WAVES")) { if (atoi(ev) == 4) h->fused_waves = CP_WAVES; }
         if (!(mf && !var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (h->d.flags & CP_FLAG_MFNN_NORM21) || h->fused_cw != 1 ||
-            h->K != CP_KMAX)
+            h->K != CP_KMAX || fused2_tasks(h->m, h->nl, 1, 8) < 256 || (h->d.flags & CP_FLAG_FP32))   // fp32 storage: 5.5 vs 6.9 ms with 4 waves
             h->fused_waves = CP_WAVES;
         h->nblk_tv = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw, h->fused_waves) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         h->curv_fused = mf && !var && h->reg == 1;

@@ -75,49 +75,51 @@ __device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, Pi
 struct ImgRsrc { cp_rsrc y1, y2a, y2b, g, u; };     // y1_k | y2_k components 0,1 | components 2,3 | grad T_k (x, y) | u_k (x, y)
 struct PrimalAt { double ux, uy, uxo, uyo, wx, wy, y1, gx, gy, v0, v1, v2, v3; };
 // what one evaluation loads: y1, grad T, the four y2 components at the position and at their adjoint neighbours, u_{n-1}
-struct ImgLoads { double y1, gx, gy, v0, v1, v2, v3, w0m, w1m, w2m, w3m, uxo, uyo, l0, l1, l2, l3; };
+template <typename S>
+struct ImgLoads { S y1, gx, gy, v0, v1, v2, v3, w0m, w1m, w2m, w3m, uxo, uyo, l0, l1, l2, l3; };   // as stored (see bld_raw)
 template <typename S, bool LINEAR>
 __device__ __forceinline__ void img_load(const MfParams &P, int i, int jg, unsigned oc, unsigned fsb, const ImgRsrc &R,
-                                         ImgLoads &q) {
+                                         ImgLoads<S> &q) {
     constexpr unsigned ES = (unsigned)sizeof(S);
     const int m = P.m;
     const unsigned oim = oc - ES, ojm = oc - ES * (unsigned)m;        // (i-1, j) and (i, j-1): inside the allocation (halo column)
-    q.y1 = bld<S>(R.y1, oc);
-    q.gx = bld<S>(R.g, oc); q.gy = bld<S>(R.g, oc, fsb);
-    q.v0 = bld<S>(R.y2a, oc); q.v1 = bld<S>(R.y2a, oc, fsb); q.v2 = bld<S>(R.y2b, oc); q.v3 = bld<S>(R.y2b, oc, fsb);
-    q.w0m = bld<S>(R.y2a, oim); q.w2m = bld<S>(R.y2b, oim);                      // Dx components: adjoint along i
-    q.w1m = bld<S>(R.y2a, ojm, fsb); q.w3m = bld<S>(R.y2b, ojm, fsb);            // Dy components: adjoint along j
-    q.uxo = bld<S>(R.u, oc);
-    q.uyo = bld<S>(R.u, oc, fsb);
-    q.l0 = q.l1 = q.l2 = q.l3 = 0.0;
+    q.y1 = bld_raw<S>(R.y1, oc);
+    q.gx = bld_raw<S>(R.g, oc); q.gy = bld_raw<S>(R.g, oc, fsb);
+    q.v0 = bld_raw<S>(R.y2a, oc); q.v1 = bld_raw<S>(R.y2a, oc, fsb); q.v2 = bld_raw<S>(R.y2b, oc); q.v3 = bld_raw<S>(R.y2b, oc, fsb);
+    q.w0m = bld_raw<S>(R.y2a, oim); q.w2m = bld_raw<S>(R.y2b, oim);                      // Dx components: adjoint along i
+    q.w1m = bld_raw<S>(R.y2a, ojm, fsb); q.w3m = bld_raw<S>(R.y2b, ojm, fsb);            // Dy components: adjoint along j
+    q.uxo = bld_raw<S>(R.u, oc);
+    q.uyo = bld_raw<S>(R.u, oc, fsb);
+    q.l0 = q.l1 = q.l2 = q.l3 = (S)0;
     if (LINEAR) {
         const unsigned oli = oc + ES * (unsigned)((m - 1) - i);
         const int dj = (jg >= P.n_global - 2) ? (P.n_global - 1) - jg : 0;
         const unsigned olj = oc + ES * (unsigned)(dj * m);
-        q.l0 = bld<S>(R.y2a, oli); q.l2 = bld<S>(R.y2b, oli);
-        q.l1 = bld<S>(R.y2a, olj, fsb); q.l3 = bld<S>(R.y2b, olj, fsb);
+        q.l0 = bld_raw<S>(R.y2a, oli); q.l2 = bld_raw<S>(R.y2b, oli);
+        q.l1 = bld_raw<S>(R.y2a, olj, fsb); q.l3 = bld_raw<S>(R.y2b, olj, fsb);
     }
 }
 template <typename S, bool LINEAR>
-__device__ __forceinline__ void img_eval(const MfParams &P, int i, int jg, const ImgLoads &q, double cnx, double cny,
+__device__ __forceinline__ void img_eval(const MfParams &P, int i, int jg, const ImgLoads<S> &q, double cnx, double cny,
                                          PrimalAt &r) {
     const int m = P.m;
-    r.y1 = q.y1; r.gx = q.gx; r.gy = q.gy; r.v0 = q.v0; r.v1 = q.v1; r.v2 = q.v2; r.v3 = q.v3; r.uxo = q.uxo; r.uyo = q.uyo;
-    const double a0 = fwd_diff_adj(q.v0, (i >= 1) ? q.w0m : 0.0, q.l0, i, m, LINEAR, P.inv_h1);
-    const double a1 = fwd_diff_adj(q.v1, (jg >= 1) ? q.w1m : 0.0, q.l1, jg, P.n_global, LINEAR, P.inv_h2);
-    const double a2 = fwd_diff_adj(q.v2, (i >= 1) ? q.w2m : 0.0, q.l2, i, m, LINEAR, P.inv_h1);
-    const double a3 = fwd_diff_adj(q.v3, (jg >= 1) ? q.w3m : 0.0, q.l3, jg, P.n_global, LINEAR, P.inv_h2);
-    const double vux = -q.gx * q.y1 + (a0 + a1);
-    const double vuy = -q.gy * q.y1 + (a2 + a3);
-    r.ux = rnd<S>((q.uxo - P.tau * vux) - cnx);  // NNE/mean_zero_indicator.m:50 (the stored value is the iterate)
-    r.uy = rnd<S>((q.uyo - P.tau * vuy) - cny);  // :53
+    r.y1 = (double)q.y1; r.gx = (double)q.gx; r.gy = (double)q.gy; r.v0 = (double)q.v0; r.v1 = (double)q.v1; r.v2 = (double)q.v2;
+    r.v3 = (double)q.v3; r.uxo = (double)q.uxo; r.uyo = (double)q.uyo;
+    const double a0 = fwd_diff_adj(r.v0, (i >= 1) ? (double)q.w0m : 0.0, (double)q.l0, i, m, LINEAR, P.inv_h1);
+    const double a1 = fwd_diff_adj(r.v1, (jg >= 1) ? (double)q.w1m : 0.0, (double)q.l1, jg, P.n_global, LINEAR, P.inv_h2);
+    const double a2 = fwd_diff_adj(r.v2, (i >= 1) ? (double)q.w2m : 0.0, (double)q.l2, i, m, LINEAR, P.inv_h1);
+    const double a3 = fwd_diff_adj(r.v3, (jg >= 1) ? (double)q.w3m : 0.0, (double)q.l3, jg, P.n_global, LINEAR, P.inv_h2);
+    const double vux = -r.gx * r.y1 + (a0 + a1);
+    const double vuy = -r.gy * r.y1 + (a2 + a3);
+    r.ux = rnd<S>((r.uxo - P.tau * vux) - cnx);  // NNE/mean_zero_indicator.m:50 (the stored value is the iterate)
+    r.uy = rnd<S>((r.uyo - P.tau * vuy) - cny);  // :53
     r.wx = -vux;
     r.wy = -vuy;
 }
 template <typename S, bool LINEAR>
 __device__ __forceinline__ void primal_u_at_b(const MfParams &P, int i, int jg, unsigned oc, unsigned fsb, const ImgRsrc &R,
                                               double cnx, double cny, PrimalAt &r) {
-    ImgLoads q;
+    ImgLoads<S> q;
     img_load<S, LINEAR>(P, i, jg, oc, fsb, R, q);
     img_eval<S, LINEAR>(P, i, jg, q, cnx, cny, r);
 }
@@ -231,6 +233,46 @@ __host__ __device__ inline long long fused2_tasks(int m, int nl, int cw = 1, int
     return (long long)fused2_geom(m, 64 / cw).parts * ((nl + waves * cw - 1) / (waves * cw));
 }
 
+// ---- hand-over of own-pixel results between the waves of a workgroup (no workgroup barrier) --------------------------------
+// Wave w+1 computes u_n, u_{n-1} at (i, j+1) as its own-pixel result of image k; wave w needs exactly these four numbers for
+// its forward differences along j. One 2 KB slot per pair of neighbouring waves ([value][lane], row i = lane in both waves)
+// and two counters: pub = number of results the producer has written, ack = number the consumer has read. The waves of a
+// workgroup walk the same (task, step, image) sequence, so the n-th result given is the n-th taken.
+//   hs_give: wait until the consumer has read result n-1 (ack >= n-1), write the four values, then pub = n;
+//   hs_take: wait until pub >= n, read the four values, then ack = n.
+// DS instructions of one wave execute in program order and the LDS serves the waves of its CU one instruction at a time,
+// so "values, then counter" on one side and "counter, then values" on the other is all the ordering there is to get; the
+// accesses are volatile so that the compiler keeps that order. No cycle: a wave gives before it takes, the last wave only
+// gives. The wait of hs_take is bounded (2^22 polls, ~0.1 s): on a time-out it acknowledges anyway and reports false, the
+// caller then loads and evaluates the position itself -- always correct, so the grid drains whatever happens; hs_give can
+// then only wait for a consumer that is guaranteed to move on.
+#ifndef CP_FUSED_HS
+#define CP_FUSED_HS 1
+#endif
+__device__ __forceinline__ void hs_give(double *slot, int *ack, int *pub, int n, int lane, double a, double b, double c,
+                                        double d) {
+    volatile int *vack = ack;
+    while (*vack < n - 1) __builtin_amdgcn_s_sleep(1);
+    volatile double *vs = slot;
+    vs[lane] = a; vs[64 + lane] = b; vs[128 + lane] = c; vs[192 + lane] = d;
+    if (lane == 0) *(volatile int *)pub = n;
+}
+__device__ __forceinline__ bool hs_take(const double *slot, int *pub, int *ack, int n, int lane, double &a, double &b,
+                                        double &c, double &d) {
+    volatile int *vpub = pub;
+    bool ok = true;
+    for (int polls = 0; *vpub < n; ++polls) {
+        if (polls > (1 << 22)) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (ok) {
+        const volatile double *vs = slot;
+        a = vs[lane]; b = vs[64 + lane]; c = vs[128 + lane]; d = vs[192 + lane];
+    }
+    if (lane == 0) *(volatile int *)ack = n;
+    return ok;
+}
+
 // KA = extent of the per-pixel image arrays (4, 8, 12 or 16 >= K): phase 1 loads, multiplies by W and stores KA images, so
 // K = 10 does not pay for 16 (the Gram tiles stay 16 x 16, zero padded). N21: F2 = mu*||.||_{2,1} (NNE/norm21.m, the
 // single-level driver) instead of the pointwise 2x2 nuclear norm.
@@ -253,6 +295,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
     // [wave][image][tile column][ux, uy, ux_old, uy_old] of the tile's first row: read (by the last row's lanes) before it is
     // rewritten within a step, in program order of the wave's own LDS instructions
     __shared__ double carry_all[NWV * CP_KMAX * CW * 4];
+    // measured at 4096^2 x 16: 8 waves with the hand-over 9.09-9.34 ms and 50.4 GB moved (31.0 GB read) per launch; 4 waves
+    // without it 9.20-9.26 ms and 57.3 GB (37.9 GB read: neighbouring waves miss the same line at the same moment and both
+    // fetch it); 4 waves with it 9.31-9.63 ms, 51.8 GB; 8 waves without it 10.2-10.6 ms
+    constexpr bool HS = (CP_FUSED_HS != 0) && !LINEAR && CW == 1 && NWV == 8;
+    __shared__ double xch_all[HS ? (NWV - 1) * 256 : 1];   // hand-over slots, one per pair of neighbouring waves
+    __shared__ int hs_flags[2 * NWV];                       // pub[wave], ack[wave]
     const int stopped = ctrl->stop;
     const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -267,7 +315,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
     if (KA < CP_KMAX) {
         for (int k = KA; k < CP_KMAX; ++k) tileA[k * CP_TS + lane] = 0.0;
     }
+    if (tid < 2 * NWV) hs_flags[tid] = 0;
     __syncthreads();
+    int *fl = hs_flags;
+    double *xl = xch_all + (HS && wave > 0 ? (wave - 1) * 256 : 0);       // slot this wave gives into (to wave - 1)
+    const double *xr = xch_all + (HS && wave < NWV - 1 ? wave * 256 : 0);  // slot this wave takes from (wave + 1)
+    int pseq = 0, cseq = 0;
     const double sigma = P.sigma, tau = P.tau, theta = P.theta, inv_sigma = 1.0 / P.sigma;
     const S *y3in = pin + 5 * (size_t)K * fs;
     S *y3out = pout + 5 * (size_t)K * fs;
@@ -300,6 +353,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
         const int nbj_lane = lane + oj * R;
         const bool wantj = LINEAR || !last_j;
         const bool rcj = wantj && !(lc + oj >= 0 && lc + oj < CW && jw + lc + oj < P.nl);
+        // hand-over roles (wave-uniform): this wave gives to wave - 1 (whose column jw - 1 is in this column group, hence active)
+        // and takes from wave + 1 if that wave has a column (jw + 1 < nl: then it is active and gives)
+        const bool hs_p = HS && wave > 0, hs_c = HS && wave < NWV - 1 && jw + 1 < P.nl;
         for (int sg = seg_hi; sg >= seg_lo; --sg) {
             const int ii = sg * R + li;
             const bool valid = ii < m && colv;
@@ -324,27 +380,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
             const unsigned offi = oi > 0 ? off + ES : off - ES;            // (i +- 1, j), only where it is recomputed
             double *cslot = carry + lc * 4;
             const double vmask = valid ? 1.0 : 0.0;
-#ifdef CP_EXP_NO_STORES   // timing experiment only: every store of phase 2 dropped by the range check
-            const unsigned off_st = 0xFFFFFFFFu;
-#else
             const unsigned off_st = valid ? off : 0xFFFFFFFFu;
-#endif
-#ifndef CP_FUSED_PIPE
-#define CP_FUSED_PIPE 0
-#endif
-            // Software pipeline over the images: the loads of image k+1 (own pixel, (i, j+1), b) are issued before the
-            // arithmetic of image k, so a wave's round trip to memory overlaps its own arithmetic and not only the other
-            // wave's of its SIMD. (The kernel is bound by the latency chain of its slowest wave -- the last wave of a
-            // workgroup, whose (i, j+1) lines nobody else streams -- not by bytes: removing the (i, j+1) loads of the other
-            // three waves changed nothing.)
-            ImgLoads q0, qj;
-            double qb;
-            if (CP_FUSED_PIPE) {
-                const ImgRsrc R0 = img_rsrc<S>(pin, g, xo, K, 0, fs);
-                img_load<S, LINEAR>(P, i, jg, off, fsb, R0, q0);
-                img_load<S, LINEAR>(P, i, jg + oj, offj, fsb, R0, qj);
-                qb = bld_stream<S>(mk_rsrc(b), off);
-            }
             for (int k = 0; k < K; ++k) {
                 // descriptors of this image's field groups (uniform: SALU); every position is one 32-bit VGPR offset
                 S *o2k = pout + ((size_t)K + 4 * (size_t)k) * fs;
@@ -353,29 +389,30 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
                               Ro1 = mk_rsrc(pout + (size_t)k * fs), Ro2a = mk_rsrc(o2k), Ro2b = mk_rsrc(o2k + 2 * fs);
                 const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
                 PrimalAt r0, rj;
-                double bb;
-                if (CP_FUSED_PIPE) {
-                    const ImgLoads c0 = q0, cj = qj;
-                    bb = qb;
-                    if (k + 1 < K) {                                   // uniform
-                        const ImgRsrc Rn = img_rsrc<S>(pin, g, xo, K, k + 1, fs);
-                        img_load<S, LINEAR>(P, i, jg, off, fsb, Rn, q0);
-                        img_load<S, LINEAR>(P, i, jg + oj, offj, fsb, Rn, qj);
-                        qb = bld_stream<S>(mk_rsrc(b + (size_t)(k + 1) * fs), off);
+                ImgLoads<S> q0, qj;
+                img_load<S, LINEAR>(P, i, jg, off, fsb, R, q0);
+                // (i, j+1): the wave of the next column computes exactly this as its own-pixel result and hands it over through
+                // LDS (hs_take below); only a wave without such a neighbour -- the last of the workgroup, the last column of a
+                // slab -- loads and evaluates the position itself. Evaluated by every lane (no lane-dependent branch).
+                if (!hs_c) img_load<S, LINEAR>(P, i, jg + oj, offj, fsb, R, qj);
+                const S bb_raw = bld_raw_stream<S>(mk_rsrc(b + (size_t)k * fs), off);
+                // fp32 storage: keep the float -> double conversions behind the whole group of loads (left alone, the compiler
+                // converts each value as it arrives into the register the next load is waiting for: one load in flight)
+                if (sizeof(S) == 4) __builtin_amdgcn_sched_barrier(0);
+                const double bb = (double)bb_raw;
+                img_eval<S, LINEAR>(P, i, jg, q0, cnx, cny, r0);
+                if (HS) {
+                    if (hs_p) hs_give(xl, fl + NWV + (wave - 1), fl + wave, ++pseq, lane, r0.ux, r0.uy, r0.uxo, r0.uyo);
+                    if (hs_c) {
+                        if (!hs_take(xr, fl + (wave + 1), fl + NWV + wave, ++cseq, lane, rj.ux, rj.uy, rj.uxo, rj.uyo)) {
+                            img_load<S, LINEAR>(P, i, jg + oj, offj, fsb, R, qj);      // never in practice: see hs_take
+                            img_eval<S, LINEAR>(P, i, jg + oj, qj, cnx, cny, rj);
+                        }
+                    } else {
+                        img_eval<S, LINEAR>(P, i, jg + oj, qj, cnx, cny, rj);
                     }
-                    __builtin_amdgcn_sched_barrier(0);                 // the prefetch is issued before image k's arithmetic
-                    img_eval<S, LINEAR>(P, i, jg, c0, cnx, cny, r0);
-                    img_eval<S, LINEAR>(P, i, jg + oj, cj, cnx, cny, rj);
                 } else {
-                    primal_u_at_b<S, LINEAR>(P, i, jg, off, fsb, R, cnx, cny, r0);
-                    // evaluated by every lane (no branch: one basic block, all loads in flight together); with CW > 1 the lanes
-                    // of all tile columns but the last touch the lines lane + R reads as its own in the same instruction group
-#ifdef CP_EXP_NO_NB        // timing experiment only (wrong results): no (i, j+1) evaluation at all
-                    rj = r0;
-#else
-                    primal_u_at_b<S, LINEAR>(P, i, jg + oj, offj, fsb, R, cnx, cny, rj);
-#endif
-                    bb = bld_stream<S>(mk_rsrc(b + (size_t)k * fs), off);
+                    img_eval<S, LINEAR>(P, i, jg + oj, qj, cnx, cny, rj);
                 }
                 const double ux = r0.ux, uy = r0.uy, uxo_ = r0.uxo, uyo_ = r0.uyo, wx = r0.wx, wy = r0.wy;
                 const double gx = r0.gx, gy = r0.gy, y1 = r0.y1, v0 = r0.v0, v1 = r0.v1, v2 = r0.v2, v3 = r0.v3;
