@@ -77,6 +77,8 @@ struct cp_engine {
     double *g = nullptr, *b = nullptr, *Tu = nullptr, *img = nullptr, *imgR = nullptr;
     double *W[3] = {nullptr, nullptr, nullptr};   // W[2] = scratch
     double *xtmp = nullptr;
+    double *vlazy[2] = {nullptr, nullptr};   // variance-TV, k_var_lazy_tv: [abar | beta] per pixel, by iteration parity
+    bool lazy_live = false;   // the y1 fields hold alpha (y1 = alpha - beta) until var_end
     double *part = nullptr, *part2 = nullptr;     // per-block partials (mf: one; pw: dual / primal)
     double *svout = nullptr;                      // k_mf_sv_eig output (16 + 256) + identity (256)
     void *ctrl = nullptr;
@@ -89,8 +91,7 @@ struct cp_engine {
     bool time_all = false;   // CP_TUNE_TIME_ALL=1: HIP events around the small kernels of the fused paths too (each pair of
                              // events costs a few microseconds of stream time; by default only the dominant kernel is timed)
     bool pw_split = false;   // tuning aid (CP_TUNE_PW_SPLIT=1): pairwise models on the split passes instead of k_pw_fused
-    int var_tiles = 2;        // template parameter NT of k_var_fused_tv (CP_TUNE_VAR_TILES = 2 | 4; 13.5 vs 19.6 ms at 4096^2 x 16)
-    bool var_fused = false;   // variance-TV: one k_var_fused_tv + k_var_efused per iteration (CP_TUNE_VAR_SPLIT=1: split passes)
+    bool var_fused = false;   // variance-TV: one k_var_lazy_tv + k_var_efused per iteration (CP_TUNE_VAR_SPLIT=1: split passes)
     int fused_cw = 1;    // image columns per wavefront of k_mf_fused_tv (template parameter CW; CP_TUNE_FUSED_CW)
     int fused_waves = CP_WAVES;   // wavefronts (adjacent columns) per workgroup of k_mf_fused_tv (NWV; CP_TUNE_FUSED_WAVES = 4 | 8)
     int nblk_tv = 0;              // its grid
@@ -244,7 +245,7 @@ extern "C" int cp_destroy(cp_handle h) {
     if (h->stage) hipFree(h->stage);
     if (h->vwarm) hipFree(h->vwarm);
     double *ptrs[] = {h->X[0], h->X[1], h->P[0], h->P[1], h->g, h->b, h->Tu, h->img, h->imgR, h->W[0], h->W[1],
-                      h->W[2], h->xtmp, h->part, h->part2, h->svout, h->hist_p, h->hist_d};
+                      h->W[2], h->xtmp, h->vlazy[0], h->vlazy[1], h->part, h->part2, h->svout, h->hist_p, h->hist_d};
     for (double *p : ptrs)
         if (p) hipFree(p);
     if (h->ctrl) hipFree(h->ctrl);
@@ -366,7 +367,6 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         h->curv_fused = mf && !var && h->reg == 1;
         h->var_fused = var && h->reg == 0 && h->nl == h->d.n_global;
         if (const char *ev = getenv("CP_TUNE_VAR_SPLIT")) { if (atoi(ev) != 0) h->var_fused = false; }
-        if (const char *ev = getenv("CP_TUNE_VAR_TILES")) { if (atoi(ev) == 4) h->var_tiles = 4; }
         if (const char *ev = getenv("CP_TUNE_CURV_SPLIT")) { if (atoi(ev) != 0) h->curv_fused = false; }
         if (mf) h->nblk_y2 = (int)std::min<long long>((curv_y2_tasks(h->m, h->nl, h->K) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         if (const char *ev = getenv("CP_TUNE_FUSED_KA")) h->fused_ka = atoi(ev) != 0;
@@ -377,6 +377,11 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
             HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
+            if (h->var_fused)
+                for (int a = 0; a < 2; ++a) {
+                    HIPCHK(hipMalloc(&h->vlazy[a], sizeof(double) * 2 * (size_t)h->fs));
+                    HIPCHK(hipMemsetAsync(h->vlazy[a], 0, sizeof(double) * 2 * (size_t)h->fs, h->stream));
+                }
             HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(std::max(h->nblk, h->nblk_fused), h->nblk_y2) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->part2, sizeof(double) * (size_t)(CP_FUSED_MAXGRID / CP_S1_GROUP) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->svout, sizeof(double) * (16 + 256 + 256)));
@@ -1030,7 +1035,7 @@ static int var_iterations(cp_engine *h, const MfParams &P, int n0, int count, in
     HIPCHK(hipGetLastError());
     return CP_OK;
 }
-// ---- fused variance-TV path: dual step 1 alone, then one k_var_fused_tv + k_var_efused per iteration -------------------
+// ---- fused variance-TV path: dual step 1 alone, then one k_var_lazy_tv + k_var_efused per iteration -------------------
 static VarEFusedArgs var_efused_args(const MfParams &P, int n, int start, int check, double tol) {
     VarEFusedArgs A;
     A.nblk = 0; A.n = n; A.start = start; A.check_stop = check; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2; A.tau = P.tau;
@@ -1042,15 +1047,18 @@ static int var_fused_start(cp_engine *h, const MfParams &P) {
     VarEFusedArgs A = var_efused_args(P, 0, 1, 0, 0.0);
     A.nblk = h->nblk;
     hipLaunchKernelGGL(k_var_efused, dim3(1), dim3(256), 0, h->stream, A, h->part, (CpCtrl *)h->ctrl, h->hist_p, h->hist_d);
+    // y_1 = alpha_1 - beta_1 with beta_1 = 0, abar_1 = mean_k y1
+    hipLaunchKernelGGL(k_var_lazy_init, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (const double *)h->P[1], h->vlazy[1]);
+    h->lazy_live = true;
     HIPCHK(hipGetLastError());
     return CP_OK;
 }
 static void launch_var_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn) {
     const bool lin = (h->d.bc == CP_BC_LINEAR);
-    auto kern = lin ? k_var_fused_tv<true, 4> : k_var_fused_tv<false, 4>;
-    if (h->var_tiles == 2) kern = lin ? k_var_fused_tv<true, 2> : k_var_fused_tv<false, 2>;
-    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, xp, xc, pc, pn, (const double *)h->g,
-                       (const double *)h->b, (const CpCtrl *)h->ctrl, h->part);
+    const int cur = (pc == h->P[1]) ? 1 : 0;
+    hipLaunchKernelGGL(lin ? k_var_lazy_tv<true> : k_var_lazy_tv<false>, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, xp, xc,
+                       pc, pn, (const double *)h->g, (const double *)h->b, (const double *)h->vlazy[cur], h->vlazy[cur ^ 1],
+                       (const CpCtrl *)h->ctrl, h->part);
 }
 static int var_fused_iterations(cp_engine *h, const MfParams &P, int n0, int count, int check, double tol) {
     for (int n = n0 + 1; n <= n0 + count; ++n) {
@@ -1069,6 +1077,10 @@ static int var_fused_iterations(cp_engine *h, const MfParams &P, int n0, int cou
 }
 static int var_end(cp_engine *h, const MfParams &P, int iterations) {
     const int fb = iterations & 1;
+    if (h->lazy_live) {   // y1 = alpha - beta in place, before the copy into the canonical buffers
+        hipLaunchKernelGGL(k_var_lazy_finish, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->P[fb], (const double *)h->vlazy[fb]);
+        h->lazy_live = false;
+    }
     hipLaunchKernelGGL(k_var_materialize, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->npf, h->X[fb], h->X[0], h->P[fb],
                        h->P[0], (const CpCtrl *)h->ctrl, fb);
     hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1]);

@@ -19,59 +19,12 @@
 #pragma once
 #include "cp_mfnn_small.cuh"
 
-// Byte offsets of the positions one thread touches (see ldo(): uniform field base + 32-bit lane offset).
-struct PixOff {
-    unsigned c, cm;      // (i, j) and (i, j-1)
-};
-
-// u_n = (u_{n-1} - tau*(A'y_n)_u) - mean  and  u_{n-1} at position (i, jg) of one image; w = -(A'y_n)_u is returned for
-// the G* monitors. y1k, y2k, gxk, uxk: uniform bases of the image's y1, first y2 component, grad-x and u_x fields
-// (grad-y / u_y one field further, the y2 components fs apart).
-// All loads are unconditional (every field has a halo column on both sides, so the +-1 element and +-1 column
-// neighbours are always inside the allocation); boundary handling happens in the arithmetic. This keeps the whole
-// per-image body one basic block, so the compiler can issue every load of the three positions before the first wait.
-template <typename S, bool LINEAR>
-__device__ __forceinline__ void primal_u_at(const MfParams &P, int i, int jg, PixOff o, unsigned fsb,
-                                            const S *__restrict__ y1k, const S *__restrict__ y2k,
-                                            const S *__restrict__ gxk, const S *__restrict__ uxk,
-                                            double cnx, double cny,
-                                            double &uxn, double &uyn, double &uxo, double &uyo, double &wx, double &wy) {
-    const int m = P.m;
-    const double y1 = ldo(y1k, o.c);
-    const double gx = ldo(gxk, o.c), gy = ldo(gxk + P.fs, o.c);
-    double adj[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const S *f = y2k + (size_t)c * P.fs;
-        const double wc = ldo(f, o.c);
-        if ((c & 1) == 0) {   // Dx component: adjoint along i
-            const double wraw = ldo(f, o.c, -(int)sizeof(S));
-            const double wm = (i >= 1) ? wraw : 0.0;
-            const double wl = LINEAR ? ldo(f, o.c + (unsigned)sizeof(S) * (unsigned)((m - 1) - i)) : 0.0;
-            adj[c] = fwd_diff_adj(wc, wm, wl, i, m, LINEAR, P.inv_h1);
-        } else {              // Dy component: adjoint along j
-            const double wraw = ldo(f, o.cm);
-            const double wm = (jg >= 1) ? wraw : 0.0;
-            double wl = 0.0;
-            if (LINEAR) {
-                const int dj = (jg >= P.n_global - 2) ? (P.n_global - 1) - jg : 0;
-                wl = ldo(f, o.c + (unsigned)sizeof(S) * (unsigned)(dj * m));
-            }
-            adj[c] = fwd_diff_adj(wc, wm, wl, jg, P.n_global, LINEAR, P.inv_h2);
-        }
-    }
-    const double vux = -gx * y1 + (adj[0] + adj[1]);
-    const double vuy = -gy * y1 + (adj[2] + adj[3]);
-    uxo = ldo(uxk, o.c);
-    uyo = ldo(uxk + P.fs, o.c);
-    uxn = rnd<S>((uxo - P.tau * vux) - cnx);  // NNE/mean_zero_indicator.m:50 (the stored value is the iterate)
-    uyn = rnd<S>((uyo - P.tau * vuy) - cny);  // :53
-    wx = -vux;
-    wy = -vuy;
-}
-
-// The same evaluation through buffer descriptors (cp_device.cuh: bld): the resources of one image's field groups and the
-// values the own-pixel evaluation loads anyway (so the dual step does not load them a second time).
+// u_n = (u_{n-1} - tau*(A'y_n)_u) - mean  and  u_{n-1} at a position (i, jg) of one image; w = -(A'y_n)_u for the G* monitors.
+// All loads are unconditional (every field has a halo column on both sides, so the +-1 element and +-1 column neighbours
+// are always inside the allocation); boundary handling happens in the arithmetic. This keeps the whole per-image body one
+// basic block, so every load of the positions is issued before the first wait.
+// Addressing goes through buffer descriptors (cp_device.cuh: bld): the resources of one image's field groups; the
+// evaluation returns the values the own-pixel position loads anyway, so the dual step does not load them a second time.
 struct ImgRsrc { cp_rsrc y1, y2a, y2b, g, u; };     // y1_k | y2_k components 0,1 | components 2,3 | grad T_k (x, y) | u_k (x, y)
 struct PrimalAt { double ux, uy, uxo, uyo, wx, wy, y1, gx, gy, v0, v1, v2, v3; };
 // what one evaluation loads: y1, grad T, the four y2 components at the position and at their adjoint neighbours, u_{n-1}

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
             srb += gx * uxb + gy * uyb;
         }
         const double mrc = src * P.invK, mrb = srb * P.invK;
-        double sy = 0.0, sgx = 0.0, sgy = 0.0, sgxy = 0.0, sgyy = 0.0;   // for the mean of the next un-projected u (cp_var_fused.cuh)
+        double sy = 0.0, sgx = 0.0, sgy = 0.0, sgxy = 0.0, sgyy = 0.0;   // for the mean of the next un-projected u (cp_var_fused.cuh: k_var_lazy_tv continues from this dual step)
 
         for (int k = 0; k < K; ++k) {
             const double *uxc = xc + (size_t)(2 * k) * fs + e, *uyc = xc + (size_t)(2 * k + 1) * fs + e;

@@ -1,99 +1,98 @@
 // Variance-TV (NNE/var_tv_registration_no_ref_ml.m): one field kernel per Chambolle-Pock iteration.
 //
-// k_var_fused_tv(n) = primal step n followed by dual step n+1 of PDO/chambolle_pock.m:162-165, per pixel, with the state
+// k_var_lazy_tv(n) = primal step n followed by dual step n+1 of PDO/chambolle_pock.m:162-165, per pixel, with the state
 // read and written once:   reads  u_{n-1} (2), y1_n (1), y2_n (4), grad T (2), B*b (1)     writes u_n (2), y1 (1), y2 (4)
-// = 17 elements per pixel-image instead of the 28 of the split passes (k_var_dual 17 + k_var_primal 11).
-// Same organisation as k_mf_fused_tv (cp_mfnn_fused.cuh): a wavefront marches along one image column in aligned segments
-// of 64 rows, (i+1, j) from lane+1 / the LDS hand-over of the previous step, (i, j+1) recomputed from y_n (read-only
-// here), four adjacent columns per workgroup, no workgroup barrier in the loop. What is different:
-//   * A = [B*diag(grad T); D]: B (mean over the K images of a pixel) enters twice. (A'y)_u,k = grad T_k * (B*y1)_k + D'y2_k
-//     needs the mean of y1 over the images at every position where the primal step is evaluated -- the own pixel and
-//     (i, j+1): one pass over the images that loads y1 at both and keeps the own values in registers. (A xbar)_1,k =
-//     (B*(grad T . ubar))_k needs the own-pixel primal step of ALL images before the first y1 update: the per-image loop
-//     runs twice, the first leaves u_n (and ubar_n) of every image in wave-private LDS tiles, the second updates y.
-//   * the mean of the next un-projected u (mean_zero_indicator, known before the pass starts as in k_mf_fused_tv):
-//     mean(u - tau*A'y) = mean(u) - tau*mean(grad T * (B*y1)) since D*1 = 0; the dual step accumulates
-//     sum_k grad T_k*(B*y1_new)_k = sum_k g_k y1_k - mean_k(y1) * sum_k g_k per pixel (VS_SGX, VS_SGY).
+// = 17 elements per pixel-image (+ 4/K for two per-pixel fields) instead of the 28 of the split passes (k_var_dual 17 +
+// k_var_primal 11). Same organisation as k_mf_fused_tv (cp_mfnn_fused.cuh): a wavefront marches along one image column in
+// aligned segments of 64 rows, (i+1, j) from lane+1 / the LDS hand-over of the previous step, (i, j+1) recomputed from y_n
+// (read-only here), four adjacent columns per workgroup, no workgroup barrier in the loop.
+// A = [B*diag(grad T); D]: B (the mean over the K images of a pixel) enters twice, and a first version (round 2,
+// k_var_fused_tv) therefore walked the images of a pixel three times (means of y1; primal step into LDS tiles; dual step):
+// 13.2-13.5 ms per iteration at 4096^2 x 16 against 14.6 ms of the split passes -- the second and third walk re-read what
+// the first had streamed out of L2 long before. The lazy form below takes both means out of the loop: 8.3 ms.
 // k_var_efused: reduction of the scalars, history rows, mean for the next pass, stop rule (no Gram, no eigensolve).
 #pragma once
 #include "cp_mfnn_fused.cuh"
 #include "cp_var.cuh"
 
-#ifndef CP_VAR_UNROLL_B
-#define CP_VAR_UNROLL_B 4
-#endif
-#ifndef CP_VAR_UNROLL_C
-#define CP_VAR_UNROLL_C 1
-#endif
 enum { VS_SGX = DS_F2S, VS_SGY = DS_SGY };   // TV only: sum of grad T * (B*y1_new) per component (DS_F2S belongs to curvature)
 
-// u_n, u_{n-1} and w = -(A'y_n)_u at (i, jg) of one image; y1c = (B*y1_n)_k at that position
+// ---- k_var_lazy_tv ------------------------------------------------------------------------------------------------------
+// B (the mean over the images) sits on both sides of y1: (A'y)_u,k = grad T_k * (y1_k - mean_k y1) and
+// (A xbar)_1,k = s_k - mean_k s, s_k = grad T_k . ubar_k. Both means can be taken out of the loop over the images:
+//   * the SSD prox of y1 is affine (NNE/SSD.m:60-61): y1+_k = c*(y1_k + sigma*(s_k - mean s)) - e*gg_k with c = lt/(1+lt),
+//     e = sigma*c, lt = mu1/sigma (c = e = sigma/(1+sigma) for the swapped call of var_tv_registration_no_ref.m:173). Store
+//     y1_k = alpha_k - beta with a per-pixel beta: alpha+_k = c*(alpha_k + sigma*s_k) - e*gg_k needs no mean, and
+//     beta+ = c*(beta + sigma*mean s) is one number per pixel, known after the loop;
+//   * B*y1 does not see beta: (B*y1)_k = alpha_k - abar, abar = mean_k alpha_k, one number per pixel written by the
+//     previous pass (read at the own pixel and at (i, j+1)).
+// The monitors of y1+ follow from per-pixel sums (sum alpha+, sum alpha+^2, sum alpha+*gg, sum gg, ...). State: alpha in the
+// y1 fields, abar and beta in two per-pixel fields, ping-ponged with the iteration parity like x and y; k_var_lazy_init
+// starts them (abar = mean y1, beta = 0), k_var_lazy_finish turns alpha back into y1. 17 elements + 4/K per pixel-image,
+// every image of a pixel loaded once. Addressing through buffer descriptors, range-dropped stores (cf. k_mf_fused_tv).
+struct VarRsrc { cp_rsrc y1, y2a, y2b, g, u; };
+struct VarLoads { double a, gx, gy, v0, v1, v2, v3, w0m, w1m, w2m, w3m, uxo, uyo, l0, l1, l2, l3; };
 template <bool LINEAR>
-__device__ __forceinline__ void var_primal_u_at(const MfParams &P, int i, int jg, PixOff o, double y1c,
-                                                const double *__restrict__ y2k, const double *__restrict__ gxk,
-                                                const double *__restrict__ uxk, double cnx, double cny, double &uxn,
-                                                double &uyn, double &uxo, double &uyo, double &wx, double &wy) {
+__device__ __forceinline__ void var_load(const MfParams &P, int i, int jg, unsigned oc, unsigned fsb, const VarRsrc &R,
+                                         VarLoads &q) {
     const int m = P.m;
-    const double gx = ldo(gxk, o.c), gy = ldo(gxk + P.fs, o.c);
-    double adj[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const double *f = y2k + (size_t)c * P.fs;
-        const double wc = ldo(f, o.c);
-        if ((c & 1) == 0) {
-            const double wraw = ldo(f, o.c, -(int)sizeof(double));
-            const double wm = (i >= 1) ? wraw : 0.0;
-            const double wl = LINEAR ? ldo(f, o.c + 8u * (unsigned)((m - 1) - i)) : 0.0;
-            adj[c] = fwd_diff_adj(wc, wm, wl, i, m, LINEAR, P.inv_h1);
-        } else {
-            const double wraw = ldo(f, o.cm);
-            const double wm = (jg >= 1) ? wraw : 0.0;
-            double wl = 0.0;
-            if (LINEAR) {
-                const int dj = (jg >= P.n_global - 2) ? (P.n_global - 1) - jg : 0;
-                wl = ldo(f, o.c + 8u * (unsigned)(dj * m));
-            }
-            adj[c] = fwd_diff_adj(wc, wm, wl, jg, P.n_global, LINEAR, P.inv_h2);
-        }
+    const unsigned oim = oc - 8u, ojm = oc - 8u * (unsigned)m;
+    q.a = bld<double>(R.y1, oc);
+    q.gx = bld<double>(R.g, oc); q.gy = bld<double>(R.g, oc, fsb);
+    q.v0 = bld<double>(R.y2a, oc); q.v1 = bld<double>(R.y2a, oc, fsb); q.v2 = bld<double>(R.y2b, oc); q.v3 = bld<double>(R.y2b, oc, fsb);
+    q.w0m = bld<double>(R.y2a, oim); q.w2m = bld<double>(R.y2b, oim);
+    q.w1m = bld<double>(R.y2a, ojm, fsb); q.w3m = bld<double>(R.y2b, ojm, fsb);
+    q.uxo = bld<double>(R.u, oc); q.uyo = bld<double>(R.u, oc, fsb);
+    q.l0 = q.l1 = q.l2 = q.l3 = 0.0;
+    if (LINEAR) {
+        const unsigned oli = oc + 8u * (unsigned)((m - 1) - i);
+        const int dj = (jg >= P.n_global - 2) ? (P.n_global - 1) - jg : 0;
+        const unsigned olj = oc + 8u * (unsigned)(dj * m);
+        q.l0 = bld<double>(R.y2a, oli); q.l2 = bld<double>(R.y2b, oli);
+        q.l1 = bld<double>(R.y2a, olj, fsb); q.l3 = bld<double>(R.y2b, olj, fsb);
     }
-    const double vux = gx * y1c + (adj[0] + adj[1]);          // k_var_primal
-    const double vuy = gy * y1c + (adj[2] + adj[3]);
-    uxo = ldo(uxk, o.c);
-    uyo = ldo(uxk + P.fs, o.c);
-    uxn = (uxo - P.tau * vux) - cnx;                           // NNE/mean_zero_indicator.m:50
-    uyn = (uyo - P.tau * vuy) - cny;                           // :53
+}
+// u_n = (u_{n-1} - tau*(A'y_n)_u) - mean at the position; abar = mean_k alpha_k there
+template <bool LINEAR>
+__device__ __forceinline__ void var_eval(const MfParams &P, int i, int jg, const VarLoads &q, double abar, double cnx, double cny,
+                                         double &ux, double &uy, double &wx, double &wy) {
+    const int m = P.m;
+    const double y1c = q.a - abar;                                             // (B*y1)_k
+    const double a0 = fwd_diff_adj(q.v0, (i >= 1) ? q.w0m : 0.0, q.l0, i, m, LINEAR, P.inv_h1);
+    const double a1 = fwd_diff_adj(q.v1, (jg >= 1) ? q.w1m : 0.0, q.l1, jg, P.n_global, LINEAR, P.inv_h2);
+    const double a2 = fwd_diff_adj(q.v2, (i >= 1) ? q.w2m : 0.0, q.l2, i, m, LINEAR, P.inv_h1);
+    const double a3 = fwd_diff_adj(q.v3, (jg >= 1) ? q.w3m : 0.0, q.l3, jg, P.n_global, LINEAR, P.inv_h2);
+    const double vux = q.gx * y1c + (a0 + a1);
+    const double vuy = q.gy * y1c + (a2 + a3);
+    ux = (q.uxo - P.tau * vux) - cnx;                                          // NNE/mean_zero_indicator.m:50
+    uy = (q.uyo - P.tau * vuy) - cny;                                          // :53
     wx = -vux;
     wy = -vuy;
 }
 
-// NT = per-image values of the own-pixel primal step kept in wave-private LDS tiles between the two per-image loops:
-//   4: u_n and ubar_n (32 KB per wave -> one workgroup per CU, 1 wave/SIMD)
-//   2: u_n only; ubar_n is rebuilt from a second load of u_{n-1} (16 KB per wave -> two workgroups per CU)
-// y1_n of the own pixel is loaded three times (mean, primal step, dual step) either way. The per-image loops are runtime
-// loops: unrolled with register arrays the kernel needed > 512 VGPRs (measured: 630 spilled at 256, 35 ms per iteration).
-template <bool LINEAR, int NT>
-__global__ __launch_bounds__(CP_BLOCK, NT == 4 ? 1 : 2) void k_var_fused_tv(MfParams P, const double *__restrict__ xo,
-                                                               double *__restrict__ xn, const double *__restrict__ pin,
-                                                               double *__restrict__ pout, const double *__restrict__ g,
-                                                               const double *__restrict__ bbar,
-                                                               const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
+template <bool LINEAR>
+__global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const double *__restrict__ xo, double *__restrict__ xn,
+                                                              const double *__restrict__ pin, double *__restrict__ pout,
+                                                              const double *__restrict__ g, const double *__restrict__ bbar,
+                                                              const double *__restrict__ lz_in, double *__restrict__ lz_out,
+                                                              const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
     constexpr int NWV = CP_WAVES;
-    __shared__ double carry_all[NWV * CP_KMAX * 4];   // [wave][image][ux, uy, uxbar, uybar] of lane 0 (see k_mf_fused_tv)
+    __shared__ double carry_all[NWV * CP_KMAX * 4];   // [wave][image][ux, uy, uxbar, uybar] of lane 0
     __shared__ double stage_all[NWV * CP_NSCAL];
-    __shared__ double tiles[NWV * NT * CP_KMAX * 64];  // [wave][ux | uy | uxbar | uybar][image][lane], wave-private
     const int stopped = ctrl->stop;
     const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
     if (stopped) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *carry = carry_all + wave * CP_KMAX * 4;
-    double *tX = tiles + wave * NT * CP_KMAX * 64, *tY = tX + CP_KMAX * 64;
-    double *tXB = tX + (NT == 4 ? 2 : 0) * CP_KMAX * 64, *tYB = tX + (NT == 4 ? 3 : 1) * CP_KMAX * 64;   // NT == 2: unused aliases
     const int K = P.K, m = P.m;
     const size_t fs = (size_t)P.fs;
     const bool linear = LINEAR;
-    const double sigma = P.sigma, theta = P.theta, inv_sigma = 1.0 / P.sigma;
-    constexpr unsigned ES = 8u;
-    const unsigned mb = ES * (unsigned)m;
+    const double sigma = P.sigma, theta = P.theta;
+    const double lt = P.mu1 / P.sigma;
+    const double cc = P.ssd_swap ? sigma / (1.0 + sigma) : lt / (1.0 + lt);   // y1+ = cc*yt - ee*gg
+    const double ee = P.ssd_swap ? sigma / (1.0 + sigma) : sigma * (lt / (1.0 + lt));
+    const unsigned mb = 8u * (unsigned)m, fsb = 8u * (unsigned)P.fs;
+    const cp_rsrc Rab = mk_rsrc(lz_in), Rbe = mk_rsrc(lz_in + fs), Rabo = mk_rsrc(lz_out), Rbeo = mk_rsrc(lz_out + fs);
 
     double sums[CP_NSUM], maxs[CP_NMAX];
 #pragma unroll
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(CP_BLOCK, NT == 4 ? 1 : 2) void k_var_fused_tv(MfPa
             const int ii = sg * 64 + lane;
             const bool valid = ii < m;
             const int i = min(ii, m - 1);
-            const unsigned off = ES * (unsigned)((j + 1) * m + i);
+            const unsigned off = 8u * (unsigned)((j + 1) * m + i);
             const bool last_i = (i == m - 1);
             const int oi = (last_i && LINEAR) ? -1 : 1;
             const int nb_lane = lane + oi;
@@ -124,109 +123,63 @@ __global__ __launch_bounds__(CP_BLOCK, NT == 4 ? 1 : 2) void k_var_fused_tv(MfPa
             const bool from_carry = want && nb_lane == 64 && sg < seg_hi;
             const bool recompute = want && (nb_lane < 0 || nb_lane > 63) && !from_carry;
             const bool any_rc = __any(recompute);
-            const PixOff p0 = {off, off - mb};
-            const PixOff pj = {oj > 0 ? off + mb : off - mb, oj > 0 ? off : off - 2u * mb};
-            const PixOff pi = {oi > 0 ? off + ES : off - ES, (oi > 0 ? off + ES : off - ES) - mb};
+            const unsigned offj = oj > 0 ? off + mb : off - mb;
+            const unsigned offi = oi > 0 ? off + 8u : off - 8u;
+            const unsigned off_st = valid ? off : 0xFFFFFFFFu;
             const double vmask = valid ? 1.0 : 0.0;
-
-            // ---- pass A: the means of y1 over the images that B needs: own pixel, (i, j +- 1), and (i +- 1, j) if recomputed --
-            double s1 = 0.0, s1j = 0.0, s1i = 0.0;
-#pragma unroll 4
-            for (int k = 0; k < K; ++k) {
-                s1 += ldo(pin + (size_t)k * fs, off);
-                s1j += ldo(pin + (size_t)k * fs, pj.c);
-            }
-            if (any_rc) {
-                for (int k = 0; k < K; ++k) s1i += ldo(pin + (size_t)k * fs, pi.c);
-            }
-            const double mean1 = s1 * P.invK, mean1j = s1j * P.invK, mean1i = s1i * P.invK;
-
-            // ---- pass B: primal step at the own pixel for every image; u_n (and ubar_n) go to the wave's LDS tiles ---------
-            double src = 0.0, srb = 0.0;
-#pragma unroll CP_VAR_UNROLL_B
+            // per-pixel state of the lazy y1: abar at the own pixel, at (i, j +- 1) (and at (i +- 1, j) where that is recomputed), beta
+            const double ab = bld<double>(Rab, off), abj = bld<double>(Rab, offj), beta = bld<double>(Rbe, off);
+            double abi = 0.0;
+            if (any_rc) abi = bld<double>(Rab, offi);
+            double S_sb = 0.0, S_sc = 0.0, D1 = 0.0, D2 = 0.0, A1 = 0.0, A2 = 0.0, AG = 0.0, G1 = 0.0, GX = 0.0, GY = 0.0, GXA = 0.0,
+                   GYA = 0.0;
             for (int k = 0; k < K; ++k) {
                 const double *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
-                const double *gxk = g + 2 * (size_t)k * fs, *uxk = xo + 2 * (size_t)k * fs;
-                double ux, uy, uxo_, uyo_, wx, wy;
-                var_primal_u_at<LINEAR>(P, i, jg, p0, ldo(pin + (size_t)k * fs, off) - mean1, y2k, gxk, uxk, cnx, cny, ux, uy, uxo_, uyo_, wx, wy);
-                const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
-                const double uxb = ux + theta * (ux - uxo_), uyb = uy + theta * (uy - uyo_);
-                tX[k * 64 + lane] = ux; tY[k * 64 + lane] = uy;
-                if (NT == 4) { tXB[k * 64 + lane] = uxb; tYB[k * 64 + lane] = uyb; }
-                src += gx * ux + gy * uy;
-                srb += gx * uxb + gy * uyb;
-                if (valid) {
-                    double *uo = xn + 2 * (size_t)k * fs;
-                    sto(uo, off, ux);
-                    sto(uo + fs, off, uy);
-                    maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], wx);
-                    maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], -wx);
-                    maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], wy);
-                    maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], -wy);
-                    sums[PS_WX] += wx;
-                    sums[DS_UX] += ux;
-                    sums[DS_UY] += uy;
-                }
-            }
-            const double mrc = src * P.invK, mrb = srb * P.invK;
-            wave_lds_sync();
-
-            // ---- pass C: dual step per image ------------------------------------------------------------------------------
-            double sy = 0.0, sgx = 0.0, sgy = 0.0, sgxy = 0.0, sgyy = 0.0;
-#pragma unroll CP_VAR_UNROLL_C
-            for (int k = 0; k < K; ++k) {
-                const double *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
-                const double *gxk = g + 2 * (size_t)k * fs, *uxk = xo + 2 * (size_t)k * fs;
-                const int nl_ = nb_lane & 63;
-                const double ux = tX[k * 64 + lane], uy = tY[k * 64 + lane];
-                double uxi = tX[k * 64 + nl_], uyi = tY[k * 64 + nl_];
-                double uxb, uyb, uxbi, uybi;
-                if (NT == 4) {
-                    uxb = tXB[k * 64 + lane]; uyb = tYB[k * 64 + lane];
-                    uxbi = tXB[k * 64 + nl_]; uybi = tYB[k * 64 + nl_];
-                } else {   // ubar_n = u_n + theta*(u_n - u_{n-1}) with u_{n-1} loaded again (own pixel and i +- 1)
-                    const double o0 = ldo(uxk, off), o1 = ldo(uxk + fs, off);
-                    const double q0 = ldo(uxk, pi.c), q1 = ldo(uxk + fs, pi.c);
-                    uxb = ux + theta * (ux - o0); uyb = uy + theta * (uy - o1);
-                    uxbi = uxi + theta * (uxi - q0); uybi = uyi + theta * (uyi - q1);
-                }
-                // (i, j +- 1): recomputed from y_n
-                double uxj, uyj, oj0, oj1, wd0, wd1;
-                var_primal_u_at<LINEAR>(P, i, jg + oj, pj, ldo(y1k, pj.c) - mean1j, y2k, gxk, uxk, cnx, cny, uxj, uyj, oj0, oj1, wd0, wd1);
-                const double uxbj = uxj + theta * (uxj - oj0), uybj = uyj + theta * (uyj - oj1);
-                // (i +- 1, j): lane +- 1's tile entry; lane 63: the hand-over of the previous step; recomputed where neither exists
+                double *o2k = pout + ((size_t)K + 4 * (size_t)k) * fs;
+                const VarRsrc R = {mk_rsrc(pin + (size_t)k * fs), mk_rsrc(y2k), mk_rsrc(y2k + 2 * fs), mk_rsrc(g + 2 * (size_t)k * fs),
+                                   mk_rsrc(xo + 2 * (size_t)k * fs)};
+                const cp_rsrc Run = mk_rsrc(xn + 2 * (size_t)k * fs), Ro1 = mk_rsrc(pout + (size_t)k * fs), Ro2a = mk_rsrc(o2k),
+                              Ro2b = mk_rsrc(o2k + 2 * fs);
+                VarLoads q0, qj;
+                var_load<LINEAR>(P, i, jg, off, fsb, R, q0);
+                var_load<LINEAR>(P, i, jg + oj, offj, fsb, R, qj);
+                const double gg = -bld_stream<double>(mk_rsrc(bbar + (size_t)k * fs), off);   // F(y, (-b), ...)   NNE/var_tv...:172
+                double ux, uy, wx, wy, uxj, uyj, wd0, wd1;
+                var_eval<LINEAR>(P, i, jg, q0, ab, cnx, cny, ux, uy, wx, wy);
+                var_eval<LINEAR>(P, i, jg + oj, qj, abj, cnx, cny, uxj, uyj, wd0, wd1);
+                const double gx = q0.gx, gy = q0.gy;
+                const double uxb = ux + theta * (ux - q0.uxo), uyb = uy + theta * (uy - q0.uyo);
+                const double uxbj = uxj + theta * (uxj - qj.uxo), uybj = uyj + theta * (uyj - qj.uyo);
+                // (i +- 1, j): lane +- 1's own result; lane 63: the hand-over of the previous step; recomputed where neither exists
+                double uxi = __shfl(ux, nb_lane), uyi = __shfl(uy, nb_lane);
+                double uxbi = __shfl(uxb, nb_lane), uybi = __shfl(uyb, nb_lane);
                 if (from_carry) { uxi = carry[4 * k]; uyi = carry[4 * k + 1]; uxbi = carry[4 * k + 2]; uybi = carry[4 * k + 3]; }
                 if (any_rc) {
                     if (recompute) {
-                        double o0, o1;
-                        var_primal_u_at<LINEAR>(P, i + oi, jg, pi, ldo(y1k, pi.c) - mean1i, y2k, gxk, uxk, cnx, cny, uxi, uyi, o0, o1, wd0, wd1);
-                        uxbi = uxi + theta * (uxi - o0);
-                        uybi = uyi + theta * (uyi - o1);
+                        VarLoads qi;
+                        var_load<LINEAR>(P, i + oi, jg, offi, fsb, R, qi);
+                        var_eval<LINEAR>(P, i + oi, jg, qi, abi, cnx, cny, uxi, uyi, wd0, wd1);
+                        uxbi = uxi + theta * (uxi - qi.uxo);
+                        uybi = uyi + theta * (uyi - qi.uyo);
                     }
                 }
                 if (lane == 0) { carry[4 * k] = ux; carry[4 * k + 1] = uy; carry[4 * k + 2] = uxb; carry[4 * k + 3] = uyb; }
-
-                const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
-                const double gg = -ldo_stream(bbar + (size_t)k * fs, off);               // F(y, (-b), ...)   NNE/var_tv...:172
-                const double y1 = ldo(y1k, off);
-                const double v0 = ldo(y2k, off), v1 = ldo(y2k + fs, off), v2 = ldo(y2k + 2 * fs, off), v3 = ldo(y2k + 3 * fs, off);
-                // ---- y1: SSD* ------------------------------------------------------------------------------------------------
-                const double a_cur = (gx * ux + gy * uy) - mrc;                          // (A x_n)_1 = B(grad T . u_n)
-                const double a_bar = (gx * uxb + gy * uyb) - mrb;
-                const double dc = a_cur - gg;
-                sums[DS_F1] += vmask * (dc * dc);                                        // NNE/SSD.m:48
-                const double yt = y1 + sigma * a_bar;
-                double y1n;
-                if (P.ssd_swap) {                                                        // NNE/var_tv_registration_no_ref.m:173
-                    y1n = yt - (yt + sigma * gg) / (1.0 + sigma);
-                } else {
-                    const double lt = P.mu1 * inv_sigma;
-                    y1n = yt - sigma * ((yt * inv_sigma + lt * gg) / (1.0 + lt));        // NNE/SSD.m:60-61 with :43
-                }
-                const double z = y1n / P.mu1;
-                sums[VS_Y1SQ] += vmask * (z * z);                                        // NNE/SSD.m:66-67
-                sums[VS_Y1G] += vmask * (z * gg);
-                sy += y1n; sgx += gx; sgy += gy; sgxy += gx * y1n; sgyy += gy * y1n;
+                bst<double>(Run, off_st, 0u, ux);
+                bst<double>(Run, off_st, fsb, uy);
+                maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], valid ? wx : -1.0e300);
+                maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], valid ? -wx : -1.0e300);
+                maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], valid ? wy : -1.0e300);
+                maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], valid ? -wy : -1.0e300);
+                sums[PS_WX] += vmask * wx;
+                sums[DS_UX] += vmask * ux;
+                sums[DS_UY] += vmask * uy;
+                // ---- y1 (lazy): alpha+ = cc*(alpha + sigma*s_bar) - ee*gg; the mean of s_bar goes into beta+ after the loop ------
+                const double s_cur = gx * ux + gy * uy, s_bar = gx * uxb + gy * uyb;
+                const double an = cc * (q0.a + sigma * s_bar) - ee * gg;
+                bst<double>(Ro1, off_st, 0u, an);
+                const double dk = s_cur - gg;
+                S_sb += s_bar; S_sc += s_cur; D1 += dk; D2 += dk * dk;
+                A1 += an; A2 += an * an; AG += an * gg; G1 += gg; GX += gx; GY += gy; GXA += gx * an; GYA += gy * an;
                 // ---- y2: norm21* ---------------------------------------------------------------------------------------------
                 const double d0 = fwd_diff(ux, uxi, uxi, last_i, linear, P.inv_h1);
                 const double d1 = fwd_diff(ux, uxj, uxj, last_j, linear, P.inv_h2);
@@ -237,21 +190,27 @@ __global__ __launch_bounds__(CP_BLOCK, NT == 4 ? 1 : 2) void k_var_fused_tv(MfPa
                 const double e2 = fwd_diff(uyb, uybi, uybi, last_i, linear, P.inv_h1);
                 const double e3 = fwd_diff(uyb, uybj, uybj, last_j, linear, P.inv_h2);
                 sums[DS_F2] += vmask * sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);      // NNE/norm21.m:56
-                const double t0 = v0 + sigma * e0, t1 = v1 + sigma * e1, t2 = v2 + sigma * e2, t3 = v3 + sigma * e3;
+                const double t0 = q0.v0 + sigma * e0, t1 = q0.v1 + sigma * e1, t2 = q0.v2 + sigma * e2, t3 = q0.v3 + sigma * e3;
                 const double nn = fmax(sqrt(t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3), P.mu2);   // :70
                 const double n0 = (P.mu2 * t0) / nn, n1 = (P.mu2 * t1) / nn, n2 = (P.mu2 * t2) / nn, n3 = (P.mu2 * t3) / nn;
-                if (valid) {
-                    double *o1 = pout + (size_t)k * fs, *o2 = pout + ((size_t)K + 4 * (size_t)k) * fs;
-                    sto(o1, off, y1n);
-                    sto(o2, off, n0); sto(o2 + fs, off, n1); sto(o2 + 2 * fs, off, n2); sto(o2 + 3 * fs, off, n3);
-                    maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3));   // :81
-                }
+                bst<double>(Ro2a, off_st, 0u, n0); bst<double>(Ro2a, off_st, fsb, n1);
+                bst<double>(Ro2b, off_st, 0u, n2); bst<double>(Ro2b, off_st, fsb, n3);
+                maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], valid ? sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3) : 0.0);   // :81
             }
-            // sum_k grad T_k * (B*y1_new)_k at this pixel: mean of the next un-projected u
-            const double my = sy * P.invK;
-            sums[VS_SGX] += vmask * (sgxy - my * sgx);
-            sums[VS_SGY] += vmask * (sgyy - my * sgy);
-            wave_lds_sync();   // tiles and hand-over of this step are complete before the next step touches them
+            // ---- per pixel: the means that B takes, the lazy offset, the monitors of y1+ = alpha+ - beta+ -------------------------
+            const double Kd = (double)K;
+            const double mrb = S_sb * P.invK, mrc = S_sc * P.invK;
+            const double bn = cc * (beta + sigma * mrb);
+            const double abn = A1 * P.invK;
+            bst<double>(Rabo, off_st, 0u, abn);
+            bst<double>(Rbeo, off_st, 0u, bn);
+            sums[DS_F1] += vmask * ((D2 - 2.0 * mrc * D1) + Kd * mrc * mrc);             // sum_k (s_k - mrc - gg_k)^2   NNE/SSD.m:48
+            const double im = 1.0 / P.mu1;
+            sums[VS_Y1SQ] += vmask * (((A2 - 2.0 * bn * A1) + Kd * bn * bn) * (im * im));   // sum_k (y1+_k/mu1)^2      NNE/SSD.m:66-67
+            sums[VS_Y1G] += vmask * ((AG - bn * G1) * im);
+            sums[VS_SGX] += vmask * (GXA - abn * GX);                                    // sum_k grad T_k * (B*y1+)_k
+            sums[VS_SGY] += vmask * (GYA - abn * GY);
+            wave_lds_sync();   // hand-over of this step is complete before the next step reads it
         }
     }
     {
@@ -277,6 +236,24 @@ __global__ __launch_bounds__(CP_BLOCK, NT == 4 ? 1 : 2) void k_var_fused_tv(MfPa
             }
             part[(size_t)blockIdx.x * CP_PSTRIDE + tid] = v;
         }
+    }
+}
+
+// lazy state from a plain y1 (abar = mean_k y1_k, beta = 0) and back (y1_k = alpha_k - beta); lz = [abar field | beta field]
+__global__ __launch_bounds__(CP_BLOCK) void k_var_lazy_init(MfParams P, const double *__restrict__ p, double *__restrict__ lz) {
+    for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
+        const int e = q + P.m;
+        double s = 0.0;
+        for (int k = 0; k < P.K; ++k) s += p[(size_t)k * P.fs + e];
+        lz[e] = s * P.invK;
+        lz[(size_t)P.fs + e] = 0.0;
+    }
+}
+__global__ __launch_bounds__(CP_BLOCK) void k_var_lazy_finish(MfParams P, double *__restrict__ p, const double *__restrict__ lz) {
+    for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
+        const int e = q + P.m;
+        const double beta = lz[(size_t)P.fs + e];
+        for (int k = 0; k < P.K; ++k) p[(size_t)k * P.fs + e] -= beta;
     }
 }
 

@@ -141,3 +141,51 @@ def test_single_level_drivers():
     # the _ml functional (pointwise 2x2 nuclear norm) on the same single level gives a different iterate
     u_nn, _, _ = od.mf_nn_registration_no_ref_ml(imgs, dict(opt2, outerIter=[2, 2], nu_factor=[0.9, 0.9]), "tv")
     assert len(u_nn) == 2
+
+
+def test_var_tv_lazy_state_over_a_long_run(monkeypatch):
+    """k_var_lazy_tv keeps y1 as alpha - beta (per-pixel beta, cp_var_fused.cuh): 300 iterations from a dual start that is not
+    mean-free over the images, against the oracle and against the split passes (no lazy state) -- the offset must not
+    drift, and the ssd_swap form of the single-level driver takes the same path"""
+    from ma_amd import engine as E, synth
+    from oracle import drivers as od, prox as px
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    m, n, k, mu = 40, 36, 4, 0.1
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    u0 = synth.smooth_displacement(m, n, k, amp=1.5).numpy().reshape(k, 2, n * m)
+    u0_ref = np.transpose(u0, (2, 1, 0))
+    omega, h = [0.0, float(m), 0.0, float(n)], (1.0, 1.0)
+    A, b, T_u, gs = od.var_problem([imgs[i] for i in range(k)], u0_ref, h, omega, "tv", "neumann")
+    tau = sigma = 0.25
+    rng = np.random.default_rng(11)
+    x0 = u0.reshape(-1)
+    y0 = 0.05 * rng.standard_normal(5 * k * m * n) + 0.02
+    iters = 300
+    Fh = lambda y, c, nargout: od.var_F(y, -b, k, h, mu, sigma, c, nargout, "tv")
+    Gh = lambda x, c, nargout: px.mean_zero_indicator(x, (m, n, k), c, nargout)
+    xr, yr, phr, dhr = cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, sigma, iters, 0.0)
+
+    def run(flags=0):
+        eng = E.Engine(E.MODEL_VAR_TV, m, n, k=k, bc="neumann", h=h, omega=omega, mu=mu, flags=flags)
+        eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+        eng.set_primal(x0)
+        eng.linearize()
+        eng.set_dual(y0)
+        eng.solve(1.0, tau, sigma, iters, 0.0)
+        out = (eng.primal(), eng.dual()) + tuple(eng.history())
+        eng.close()
+        return out
+
+    xl, yl, phl, dhl = run()
+    assert _rel(xl, xr) < 1e-9 and _rel(yl, yr) < 1e-9
+    np.testing.assert_allclose(phl, phr, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(dhl, dhr, rtol=1e-8, atol=1e-10)
+    monkeypatch.setenv("CP_TUNE_VAR_SPLIT", "1")
+    xs, ys, phs, dhs = run()
+    assert _rel(xl, xs) < 1e-11 and _rel(yl, ys) < 1e-11
+    np.testing.assert_allclose(phl, phs, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(dhl, dhs, rtol=1e-10, atol=1e-12)
+    xs2, ys2, _, _ = run(E.FLAG_VAR_SSD_SWAP)
+    monkeypatch.delenv("CP_TUNE_VAR_SPLIT")
+    xl2, yl2, _, _ = run(E.FLAG_VAR_SSD_SWAP)
+    assert _rel(xl2, xs2) < 1e-11 and _rel(yl2, ys2) < 1e-11
