@@ -123,9 +123,9 @@ def parse():
 
 
 def cpu_baseline(size, k, iters, reg):
-    """The C + OpenMP restatement of the same iteration (oracle/cp_nntv.c: matrix-free, all host threads) timed on a
-    bounded sample of the workload; the curvature model falls back to the numpy restatement (reference-shaped: sparse
-    A, SpMV, LAPACK SVD). Returns (iterations/s at the sample size, seconds, threads, description)."""
+    """The C + OpenMP restatement of the same iteration (oracle/cp_nntv.c: matrix-free, all host threads; NN-TV and
+    NN-curvature) timed on a bounded sample of the workload. Returns (iterations/s at the sample size, seconds, threads,
+    description)."""
     from ma_amd import synth
     from oracle import drivers as od, operators as oo
     m = n = size
@@ -136,33 +136,24 @@ def cpu_baseline(size, k, iters, reg):
     h = (1.0, 1.0)
     mu, nu, tau, sigma = 0.2, 0.9 * 2.0 * k, 0.3, 0.3
     kmn = k * m * n
-    if reg == "tv":
-        from oracle import c_oracle
-        g = np.empty(2 * kmn)
-        b = np.empty(kmn)
-        T_u = np.empty((m, n, k))
-        for i in range(k):
-            T_u[:, :, i], gi = oo.evaluate_displacement(imgs[i], h, u0_ref[:, :, i], omega)
-            g[2 * i * m * n: 2 * (i + 1) * m * n] = gi.reshape(-1, order="F")
-            b[i * m * n: (i + 1) * m * n] = T_u[:, :, i].reshape(-1, order="F") - \
-                (gi[:, 0] * u0_ref[:, 0, i] + gi[:, 1] * u0_ref[:, 1, i])
-        x0 = np.concatenate([u0.reshape(-1), T_u.reshape(-1, order="F")])
-        y0 = np.zeros(6 * kmn)
-        c_oracle.nntv_chambolle_pock(m, n, k, "neumann", h, mu, nu, 1.0, tau, sigma, 1, None, g, b, x0, y0)   # warm-up
-        t0 = time.perf_counter()
-        c_oracle.nntv_chambolle_pock(m, n, k, "neumann", h, mu, nu, 1.0, tau, sigma, iters, None, g, b, x0, y0)
-        dt = time.perf_counter() - t0
-        return iters / dt, dt, c_oracle.threads(), "C + OpenMP restatement oracle/cp_nntv.c (matrix-free, Gram + Jacobi SVD)"
-    A, b, T_u, _ = od.mf_nn_problem([imgs[i] for i in range(k)], u0_ref, h, omega, reg, "neumann")
-    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    from oracle import c_oracle
+    bc, mu = ("neumann", mu) if reg == "tv" else ("dirichlet", 20.0)
+    g = np.empty(2 * kmn)
+    b = np.empty(kmn)
+    T_u = np.empty((m, n, k))
+    for i in range(k):
+        T_u[:, :, i], gi = oo.evaluate_displacement(imgs[i], h, u0_ref[:, :, i], omega)
+        g[2 * i * m * n: 2 * (i + 1) * m * n] = gi.reshape(-1, order="F")
+        b[i * m * n: (i + 1) * m * n] = T_u[:, :, i].reshape(-1, order="F") - \
+            (gi[:, 0] * u0_ref[:, 0, i] + gi[:, 1] * u0_ref[:, 1, i])
     x0 = np.concatenate([u0.reshape(-1), T_u.reshape(-1, order="F")])
-    y0 = np.zeros(4 * kmn)
-    Fh = lambda y, c, nargout: od.mf_nn_F(y, b, k, h, mu, nu, sigma, c, nargout, reg)
-    Gh = lambda x, c, nargout: od.mf_nn_G(x, (m, n, k), c, nargout)
+    solve = c_oracle.nntv_chambolle_pock if reg == "tv" else c_oracle.nncurv_chambolle_pock
+    y0 = np.zeros((6 if reg == "tv" else 4) * kmn)
+    solve(m, n, k, bc, h, mu, nu, 1.0, tau, sigma, 1, None, g, b, x0, y0)   # warm-up
     t0 = time.perf_counter()
-    cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, sigma, iters, 0.0)
+    solve(m, n, k, bc, h, mu, nu, 1.0, tau, sigma, iters, None, g, b, x0, y0)
     dt = time.perf_counter() - t0
-    return iters / dt, dt, 1, "numpy/scipy restatement (reference-shaped: sparse A, 4 SpMV + 3 SVD per iteration)"
+    return iters / dt, dt, c_oracle.threads(), "C + OpenMP restatement oracle/cp_nntv.c (matrix-free, Gram + Jacobi SVD)"
 
 
 def main_batch(args):
@@ -375,7 +366,7 @@ def main():
                          "hbm_frac_of_measured_copy": (traffic / dual_avg_s / max(copy_gbs.values())) if (traffic and dual_avg_s > 0 and copy_gbs) else None},
         }
         if not args.no_cpu_baseline:
-            csize, citers = (args.cpu_size, args.cpu_iters) if reg == "tv" else (min(args.cpu_size, 256), min(args.cpu_iters, 6))
+            csize, citers = args.cpu_size, args.cpu_iters
             cits, cdt, ccores, cdesc = cpu_baseline(csize, k, citers, reg)
             scale = (csize * csize) / float(m * n)
             out["cpu_baseline"] = {
