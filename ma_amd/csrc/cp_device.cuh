@@ -6,6 +6,7 @@
 #define CP_BLOCK 256          // threads per workgroup (4 waves)
 #define CP_WAVES (CP_BLOCK / 64)
 #define CP_KMAX 16            // max images per mf_nn problem (one 16x16 f64 MFMA tile)
+#define CP_VAR_KMAX 64        // max images of the variance models (no K x K spectral work: only the LDS hand-over row scales with K)
 #define CP_TS 66              // LDS tile row stride (doubles): conflict-free ds_read_b64 in MFMA order
 #define CP_NSUM 12            // per-pass partial sums   (slots 0..11)
 #define CP_NMAX 8             // per-pass partial maxima (slots 12..19)

@@ -267,7 +267,10 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
     const bool pw = (d.model == CP_MODEL_TV_L1_DENOISE || d.model == CP_MODEL_TV_L1_REG || d.model == CP_MODEL_TV_L2_REG);
     if (!mf && !pw) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg unknown model %d", d.model);
     if (mf) {
-        if (d.k < 1 || d.k > CP_KMAX) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported k = %d (1..%d)", d.k, CP_KMAX);
+        // the nuclear-norm models do their K x K spectral work on one 16 x 16 MFMA tile / one-wave Jacobi; the variance models
+        // have none and take up to CP_VAR_KMAX images (the reference's real data sets have k = size(data, 3) frames)
+        const int kmax = var ? CP_VAR_KMAX : CP_KMAX;
+        if (d.k < 1 || d.k > kmax) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported k = %d (1..%d)", d.k, kmax);
         if ((d.model == CP_MODEL_MF_NN_TV || d.model == CP_MODEL_VAR_TV) && d.bc != CP_BC_NEUMANN && d.bc != CP_BC_LINEAR)
             CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");   // finite_difference_operator.m:35
         if (d.bc < 0 || d.bc > 2) CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");

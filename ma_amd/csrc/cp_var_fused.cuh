@@ -77,13 +77,13 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const d
                                                               const double *__restrict__ lz_in, double *__restrict__ lz_out,
                                                               const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
     constexpr int NWV = CP_WAVES;
-    __shared__ double carry_all[NWV * CP_KMAX * 4];   // [wave][image][ux, uy, uxbar, uybar] of lane 0
+    __shared__ double carry_all[NWV * CP_VAR_KMAX * 4];   // [wave][image][ux, uy, uxbar, uybar] of lane 0
     __shared__ double stage_all[NWV * CP_NSCAL];
     const int stopped = ctrl->stop;
     const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
     if (stopped) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *carry = carry_all + wave * CP_KMAX * 4;
+    double *carry = carry_all + wave * CP_VAR_KMAX * 4;
     const int K = P.K, m = P.m;
     const size_t fs = (size_t)P.fs;
     const bool linear = LINEAR;

@@ -11,6 +11,9 @@ def test_create_errors():
         E.Engine(E.MODEL_MF_NN_TV, 16, 16, k=3, bc="dirichlet")
     with pytest.raises(E.CpEngineError, match="unsupported"):
         E.Engine(E.MODEL_MF_NN_TV, 16, 16, k=17)
+    E.Engine(E.MODEL_VAR_TV, 16, 16, k=64).close()              # variance models: up to 64 images
+    with pytest.raises(E.CpEngineError, match="unsupported"):
+        E.Engine(E.MODEL_VAR_TV, 16, 16, k=65)
     with pytest.raises(E.CpEngineError, match="badArg"):
         E.Engine(E.MODEL_TV_L1_REG, 1, 16)
     with pytest.raises(E.CpEngineError, match="badArg"):

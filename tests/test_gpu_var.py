@@ -13,7 +13,9 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("reg,bc,m,n,k,mu", [("tv", "neumann", 48, 40, 3, 0.1), ("tv", "linear", 33, 50, 4, 0.1),
                                              ("curvature", "dirichlet", 40, 36, 3, 5.0),
-                                             ("curvature", "neumann", 70, 55, 5, 5.0), ("tv", "neumann", 64, 64, 16, 0.1)])
+                                             ("curvature", "neumann", 70, 55, 5, 5.0), ("tv", "neumann", 64, 64, 16, 0.1),
+                                             # more than 16 images: the variance models have no K x K spectral work (limit 64)
+                                             ("tv", "neumann", 40, 33, 21, 0.1), ("curvature", "dirichlet", 36, 40, 18, 5.0)])
 def test_var_solve_matches_oracle(reg, bc, m, n, k, mu):
     from ma_amd import engine as E, synth
     from oracle import drivers as od, prox as px
