@@ -79,3 +79,23 @@ if "c3" in which:
         print(json.dumps({"workload": f"C3 mf_nn_tv_registration_no_ref_ml K=10 1024^2, {D.num_levels(m, n)} levels, {tag}",
                           "seconds": dt, "cp_iterations": its, "power_iterations": pw, "outer_iterations": len(keep),
                           "cp_it_per_s_whole_driver": its / dt}), flush=True)
+
+if "c4drv" in which:
+    # C4 as worded: the whole mf_nn_curvature_registration_no_ref_ml driver, K = 16 synthetic 4096^2 templates, all levels, one GPU
+    # (parameters of the kidney case of NNE/demo_mf_nn_curvature_registration_no_ref_ml.m:72-79)
+    from ma_amd import drivers as D
+    m = n = int(os.environ.get("C4_SIZE", "4096")); k = 16
+    imgs = synth.dynamic_test_image(m, n, k, device=torch.device("cuda", 0)).cpu().numpy()
+    torch.cuda.empty_cache()
+    optPara = dict(theta=1.0, maxIter=2000, tol=5e-3, outerIter=[16, 2], mu=2e1, nu_factor=[0.95, 0.95], bc="dirichlet", doPlots=False)
+    keep = {}
+    t0 = time.perf_counter()
+    D._mf_nn_ml([imgs[i] for i in range(k)], optPara, "curvature", keep=keep, download_all=False)
+    dt = time.perf_counter() - t0
+    its = sum(v["iterations"] for v in keep.values())
+    per_level = {}
+    for (lev, o), v in keep.items():
+        per_level[lev] = per_level.get(lev, 0) + v["iterations"]
+    print(json.dumps({"workload": f"C4 mf_nn_curvature_registration_no_ref_ml K=16 {m}^2, {D.num_levels(m, n)} levels, fp64, one GPU",
+                      "seconds": dt, "cp_iterations": its, "iterations_per_level": per_level,
+                      "power_iterations": sum(v["n_power"] for v in keep.values()), "outer_iterations": len(keep)}), flush=True)
