@@ -274,6 +274,14 @@ __device__ __forceinline__ void proj_spectral_2x2(double m11, double m21, double
     s1 = inside ? sv1 : mu;
 }
 
+// row sum of the 5-point Laplacian at pixel (i, jg): 0 in the interior and for neumann rows
+// (NNE/discrete_laplacian.m:25-27: diagonal -1/h^2 at the ends), -1/h^2 per missing neighbour for dirichlet rows (:28)
+__device__ __forceinline__ double lap_rowsum(bool neumann, bool first_i, bool last_i, bool first_j, bool last_j, double ih1,
+                                             double ih2) {
+    if (neumann) return 0.0;
+    return -((first_i ? 1.0 : 0.0) + (last_i ? 1.0 : 0.0)) * ih1 - ((first_j ? 1.0 : 0.0) + (last_j ? 1.0 : 0.0)) * ih2;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward difference along one axis with the reference's boundary rows
 // (NNE/finite_difference_operator.m:29-36): interior (u_next - u)/h; last row neumann 0,

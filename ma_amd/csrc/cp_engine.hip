@@ -368,7 +368,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             h->fused_waves = CP_WAVES;
         h->nblk_tv = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw, h->fused_waves) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         h->curv_fused = mf && !var && h->reg == 1;
-        h->var_fused = var && h->reg == 0 && h->nl == h->d.n_global;
+        h->var_fused = var && h->nl == h->d.n_global;
         if (const char *ev = getenv("CP_TUNE_VAR_SPLIT")) { if (atoi(ev) != 0) h->var_fused = false; }
         if (const char *ev = getenv("CP_TUNE_CURV_SPLIT")) { if (atoi(ev) != 0) h->curv_fused = false; }
         if (mf) h->nblk_y2 = (int)std::min<long long>((curv_y2_tasks(h->m, h->nl, h->K) + 7) / 8 * 8, CP_FUSED_MAXGRID);
@@ -1042,13 +1042,13 @@ static int var_iterations(cp_engine *h, const MfParams &P, int n0, int count, in
 static VarEFusedArgs var_efused_args(const MfParams &P, int n, int start, int check, double tol) {
     VarEFusedArgs A;
     A.nblk = 0; A.n = n; A.start = start; A.check_stop = check; A.tol = tol; A.mu1 = P.mu1; A.mu2 = P.mu2; A.tau = P.tau;
-    A.Ntot = P.Ntot;
+    A.Ntot = P.Ntot; A.reg = 0;
     return A;
 }
 static int var_fused_start(cp_engine *h, const MfParams &P) {
     launch_var_dual<0>(h, P, h->X[0], h->X[1], h->P[0], h->P[1], 0, 1);                 // y_1 from xbar_0 = x_0
     VarEFusedArgs A = var_efused_args(P, 0, 1, 0, 0.0);
-    A.nblk = h->nblk;
+    A.nblk = h->nblk; A.reg = h->reg;
     hipLaunchKernelGGL(k_var_efused, dim3(1), dim3(256), 0, h->stream, A, h->part, (CpCtrl *)h->ctrl, h->hist_p, h->hist_d);
     // y_1 = alpha_1 - beta_1 with beta_1 = 0, abar_1 = mean_k y1
     hipLaunchKernelGGL(k_var_lazy_init, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (const double *)h->P[1], h->vlazy[1]);
@@ -1059,6 +1059,13 @@ static int var_fused_start(cp_engine *h, const MfParams &P) {
 static void launch_var_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn) {
     const bool lin = (h->d.bc == CP_BC_LINEAR);
     const int cur = (pc == h->P[1]) ? 1 : 0;
+    if (h->reg != 0) {
+        const bool neu = (h->d.bc == CP_BC_NEUMANN);
+        hipLaunchKernelGGL(neu ? k_var_lazy_curv<true> : k_var_lazy_curv<false>, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, xp,
+                           xc, pc, pn, (const double *)h->g, (const double *)h->b, (const double *)h->vlazy[cur], h->vlazy[cur ^ 1],
+                           (const CpCtrl *)h->ctrl, h->part);
+        return;
+    }
     hipLaunchKernelGGL(lin ? k_var_lazy_tv<true> : k_var_lazy_tv<false>, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, xp, xc,
                        pc, pn, (const double *)h->g, (const double *)h->b, (const double *)h->vlazy[cur], h->vlazy[cur ^ 1],
                        (const CpCtrl *)h->ctrl, h->part);
@@ -1070,10 +1077,22 @@ static int var_fused_iterations(cp_engine *h, const MfParams &P, int n0, int cou
         launch_var_fused(h, P, h->X[prv], h->X[cur], h->P[cur], h->P[nxt]);
         CPCHK(timer_end(h, T_DUAL));
         VarEFusedArgs A = var_efused_args(P, n, 0, check, tol);
+        A.reg = h->reg;
         if (h->time_all) CPCHK(timer_begin(h, T_EIG));
         const double *rows = staged_partials(h, h->nblk_fused, &A.nblk, true);
         hipLaunchKernelGGL(k_var_efused, dim3(1), dim3(256), 0, h->stream, A, rows, (CpCtrl *)h->ctrl, h->hist_p, h->hist_d);
         if (h->time_all) CPCHK(timer_end(h, T_EIG));
+        if (h->reg != 0) {   // variance-curvature: y2_{n+1} (the kernel of the NN-curvature model), then F2 / F2* / boundary term / stop rule
+            CPCHK(timer_begin(h, T_PRIMAL));
+            launch_curv_y2_t<double>(h, P, h->X[cur], h->X[prv], h->P[cur], h->P[nxt]);
+            CPCHK(timer_end(h, T_PRIMAL));
+            CurvFinArgs F;
+            F.n = n; F.check_stop = check; F.tol = tol; F.mu2 = P.mu2; F.tau = P.tau; F.Ntot = P.Ntot;
+            if (h->time_all) CPCHK(timer_begin(h, T_FIN));
+            const double *rows2 = staged_partials(h, h->nblk_y2, &F.nblk, true);
+            hipLaunchKernelGGL(k_var_curv_fin, dim3(1), dim3(256), 0, h->stream, F, rows2, (CpCtrl *)h->ctrl, h->hist_p, h->hist_d);
+            if (h->time_all) CPCHK(timer_end(h, T_FIN));
+        }
     }
     HIPCHK(hipGetLastError());
     return CP_OK;

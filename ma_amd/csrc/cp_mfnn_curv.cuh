@@ -19,13 +19,6 @@
 #include "cp_var.cuh"   // reduce_scalars
 
 
-// row sum of the 5-point Laplacian at pixel (i, jg): 0 in the interior and for neumann rows
-// (NNE/discrete_laplacian.m:25-27: diagonal -1/h^2 at the ends), -1/h^2 per missing neighbour for dirichlet rows (:28)
-__device__ __forceinline__ double lap_rowsum(bool neumann, bool first_i, bool last_i, bool first_j, bool last_j, double ih1,
-                                             double ih2) {
-    if (neumann) return 0.0;
-    return -((first_i ? 1.0 : 0.0) + (last_i ? 1.0 : 0.0)) * ih1 - ((first_j ? 1.0 : 0.0) + (last_j ? 1.0 : 0.0)) * ih2;
-}
 
 // Same organisation as k_mf_fused_tv: a wave marches down one image column in segments of 64 rows, four adjacent
 // columns per workgroup, no workgroup barrier in the loop. y2_n at (i+1, j) is lane+1's own value (lane 63: the value

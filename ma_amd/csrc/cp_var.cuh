@@ -223,6 +223,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
                 }
                 const double z0 = n0 / P.mu2, z1 = n1 / P.mu2;
                 sums[DS_F2S] += z0 * z0 + z1 * z1;
+                if (MODE == 0) {   // sum of y2_new * rowsum(Lap): mean(Lap y2_new) for the fused path that continues from here
+                    const double rs = lap_rowsum(neumann, first_i, last_i, first_j, last_j, ih1, ih2);
+                    sums[DS_BSX] += n0 * rs;
+                    sums[DS_BSY] += n1 * rs;
+                }
             }
             sums[DS_UX] += ux;
             sums[DS_UY] += uy;
@@ -230,6 +235,10 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
         if (REG == 0) {   // sum_k grad T_k * (B*y1_new)_k (slots VS_SGX = DS_F2S, VS_SGY = DS_SGY; DS_F2S belongs to curvature)
             const double my = sy * P.invK;
             sums[DS_F2S] += sgxy - my * sgx;
+            sums[DS_SGY] += sgyy - my * sgy;
+        } else {          // curvature: DS_F2S holds F2*(y2); the x component goes to slot 11 (VSC_SGX, cp_var_fused.cuh)
+            const double my = sy * P.invK;
+            sums[11] += sgxy - my * sgx;
             sums[DS_SGY] += sgyy - my * sgy;
         }
     }

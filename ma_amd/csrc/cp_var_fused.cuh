@@ -13,9 +13,11 @@
 // k_var_efused: reduction of the scalars, history rows, mean for the next pass, stop rule (no Gram, no eigensolve).
 #pragma once
 #include "cp_mfnn_fused.cuh"
+#include "cp_mfnn_curv.cuh"
 #include "cp_var.cuh"
 
-enum { VS_SGX = DS_F2S, VS_SGY = DS_SGY };   // TV only: sum of grad T * (B*y1_new) per component (DS_F2S belongs to curvature)
+enum { VS_SGX = DS_F2S, VS_SGY = DS_SGY };   // sum of grad T * (B*y1_new) per component (field kernels of the fused paths)
+enum { VSC_SGX = 11 };                       // the same, x component, from k_var_dual<., 1> (there DS_F2S holds F2*(y2))
 
 // ---- k_var_lazy_tv ------------------------------------------------------------------------------------------------------
 // B (the mean over the images) sits on both sides of y1: (A'y)_u,k = grad T_k * (y1_k - mean_k y1) and
@@ -239,6 +241,161 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const d
     }
 }
 
+// ---- variance-curvature (NNE/var_curvature_registration_no_ref_ml.m): two field passes per iteration -------------------------
+// A = [B*diag(grad T); Lap], F2 = SSD(y2, 0). As for NN-curvature (cp_mfnn_curv.cuh) the iteration is split where the stencils
+// are: k_var_lazy_curv(n) = primal step n (u_n from Lap y2_n, read-only here) + the lazy y1 update of k_var_lazy_tv
+// (reads alpha u(2) y2(2) grad T(2) b, writes u(2) alpha = 11 elements), k_var_efused(n) (reg = 1), then k_curv_y2(n) --
+// the very kernel of the NN-curvature model: u is the first 2K fields of x and y2 follows the K fields of y1 in both --
+// (8 elements) and k_var_curv_fin(n). 19 elements instead of the 17 + 9 of the split passes, no position recomputed.
+template <bool NEUMANN>
+__global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_curv(MfParams P, const double *__restrict__ xo, double *__restrict__ xn,
+                                                                const double *__restrict__ pin, double *__restrict__ pout,
+                                                                const double *__restrict__ g, const double *__restrict__ bbar,
+                                                                const double *__restrict__ lz_in, double *__restrict__ lz_out,
+                                                                const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
+    constexpr int NWV = CP_WAVES;
+    __shared__ double carry_all[NWV * 2 * CP_VAR_KMAX * 2];   // [wave][step parity][image][y2 component] of lane 0
+    __shared__ double stage_all[NWV * CP_NSCAL];
+    const int stopped = ctrl->stop;
+    const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
+    if (stopped) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *carry = carry_all + wave * 2 * CP_VAR_KMAX * 2;
+    const int K = P.K, m = P.m;
+    const size_t fs = (size_t)P.fs;
+    const double sigma = P.sigma, theta = P.theta, tau = P.tau;
+    const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
+    const double lt = P.mu1 / P.sigma;
+    const double cc = lt / (1.0 + lt), ee = sigma * (lt / (1.0 + lt));   // y1+ = cc*yt - ee*gg  (NNE/SSD.m:60-61)
+    const unsigned mb = 8u * (unsigned)m, fsb = 8u * (unsigned)P.fs;
+    const cp_rsrc Rab = mk_rsrc(lz_in), Rbe = mk_rsrc(lz_in + fs), Rabo = mk_rsrc(lz_out), Rbeo = mk_rsrc(lz_out + fs);
+
+    double sums[CP_NSUM], maxs[CP_NMAX];
+#pragma unroll
+    for (int a = 0; a < CP_NSUM; ++a) sums[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < CP_NMAX; ++a) maxs[a] = -1.0e300;
+    maxs[DM_S1 - CP_NSUM] = 0.0;
+
+    const Fused2Geom GM = fused2_geom(m);
+    const int ntasks = GM.parts * ((P.nl + NWV - 1) / NWV);
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const int cg = task / GM.parts, pt = task - cg * GM.parts;
+        const int j = cg * NWV + wave;
+        if (j >= P.nl) continue;                                   // wave-uniform
+        const int seg_lo = pt * GM.steps, seg_hi = min(seg_lo + GM.steps, GM.nseg) - 1;
+        const int jg = P.j_off + j;
+        const bool first_j = (jg == 0), last_j = (jg == P.n_global - 1);
+        for (int sg = seg_hi; sg >= seg_lo; --sg) {
+            const int par = (seg_hi - sg) & 1;
+            const int ii = sg * 64 + lane;
+            const bool valid = ii < m;
+            const int i = min(ii, m - 1);
+            const unsigned off = 8u * (unsigned)((j + 1) * m + i);
+            const unsigned off_st = valid ? off : 0xFFFFFFFFu;
+            const bool first_i = (i == 0), last_i = (i == m - 1);
+            const bool want = valid && !last_i;                    // y2_n at (i+1, j) is used
+            const bool from_carry = want && lane == 63 && sg < seg_hi;
+            const bool reload = want && lane == 63 && sg == seg_hi;
+            const bool any_reload = __any(reload);                 // wave-uniform: first step of a part below the image's top
+            const double *cin = carry + (par ^ 1) * CP_VAR_KMAX * 2;
+            double *cout_ = carry + par * CP_VAR_KMAX * 2;
+            const double vmask = valid ? 1.0 : 0.0;
+            const double ab = bld<double>(Rab, off), beta = bld<double>(Rbe, off);
+            double S_sb = 0.0, S_sc = 0.0, D1 = 0.0, D2 = 0.0, A1 = 0.0, A2 = 0.0, AG = 0.0, G1 = 0.0, GX = 0.0, GY = 0.0, GXA = 0.0,
+                   GYA = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const cp_rsrc Ry1 = mk_rsrc(pin + (size_t)k * fs), Ry2 = mk_rsrc(pin + ((size_t)K + 2 * (size_t)k) * fs),
+                              Rg = mk_rsrc(g + 2 * (size_t)k * fs), Ru = mk_rsrc(xo + 2 * (size_t)k * fs),
+                              Run = mk_rsrc(xn + 2 * (size_t)k * fs), Ro1 = mk_rsrc(pout + (size_t)k * fs);
+                const double al = bld<double>(Ry1, off);
+                const double gx = bld<double>(Rg, off), gy = bld<double>(Rg, off, fsb);
+                const double gg = -bld_stream<double>(mk_rsrc(bbar + (size_t)k * fs), off);   // F(y, (-b), ...)   NNE/var_curvature...:131
+                const double uxo_ = bld_stream<double>(Ru, off), uyo_ = bld_stream<double>(Ru, off, fsb);
+                double lap[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const unsigned so = c ? fsb : 0u;
+                    const double w0 = bld<double>(Ry2, off, so);
+                    const double wim = bld<double>(Ry2, off - 8u, so);
+                    const double wjm = bld<double>(Ry2, off - mb, so), wjp = bld<double>(Ry2, off + mb, so);
+                    double wip = __shfl(w0, lane + 1);
+                    if (from_carry) wip = cin[2 * k + c];
+                    if (any_reload) {
+                        if (reload) wip = bld<double>(Ry2, off + 8u, so);
+                    }
+                    if (lane == 0) cout_[2 * k + c] = w0;
+                    // NNE/discrete_laplacian.m:23-46: a missing neighbour is the centre value (neumann) or zero (dirichlet)
+                    const double a0 = !first_i ? wim : (NEUMANN ? w0 : 0.0);
+                    const double a1 = !last_i ? wip : (NEUMANN ? w0 : 0.0);
+                    const double a2 = !first_j ? wjm : (NEUMANN ? w0 : 0.0);
+                    const double a3 = !last_j ? wjp : (NEUMANN ? w0 : 0.0);
+                    lap[c] = (a0 + a1 - 2.0 * w0) * ih1 + (a2 + a3 - 2.0 * w0) * ih2;
+                }
+                const double y1c = al - ab;                                        // (B*y1)_k
+                const double vux = gx * y1c + lap[0];                              // (A'y)_u = grad T * (B*y1) + Lap y2
+                const double vuy = gy * y1c + lap[1];
+                const double ux = (uxo_ - tau * vux) - cnx;                        // NNE/mean_zero_indicator.m:50,53
+                const double uy = (uyo_ - tau * vuy) - cny;
+                const double wx = -vux, wy = -vuy;
+                bst<double>(Run, off_st, 0u, ux);
+                bst<double>(Run, off_st, fsb, uy);
+                maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], valid ? wx : -1.0e300);
+                maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], valid ? -wx : -1.0e300);
+                maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], valid ? wy : -1.0e300);
+                maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], valid ? -wy : -1.0e300);
+                sums[PS_WX] += vmask * wx;
+                sums[DS_UX] += vmask * ux;
+                sums[DS_UY] += vmask * uy;
+                const double uxb = ux + theta * (ux - uxo_), uyb = uy + theta * (uy - uyo_);
+                const double s_cur = gx * ux + gy * uy, s_bar = gx * uxb + gy * uyb;
+                const double an = cc * (al + sigma * s_bar) - ee * gg;
+                bst<double>(Ro1, off_st, 0u, an);
+                const double dk = s_cur - gg;
+                S_sb += s_bar; S_sc += s_cur; D1 += dk; D2 += dk * dk;
+                A1 += an; A2 += an * an; AG += an * gg; G1 += gg; GX += gx; GY += gy; GXA += gx * an; GYA += gy * an;
+            }
+            const double Kd = (double)K;
+            const double mrb = S_sb * P.invK, mrc = S_sc * P.invK;
+            const double bn = cc * (beta + sigma * mrb);
+            const double abn = A1 * P.invK;
+            bst<double>(Rabo, off_st, 0u, abn);
+            bst<double>(Rbeo, off_st, 0u, bn);
+            sums[DS_F1] += vmask * ((D2 - 2.0 * mrc * D1) + Kd * mrc * mrc);             // sum_k (s_k - mrc - gg_k)^2   NNE/SSD.m:48
+            const double im = 1.0 / P.mu1;
+            sums[VS_Y1SQ] += vmask * (((A2 - 2.0 * bn * A1) + Kd * bn * bn) * (im * im));   // NNE/SSD.m:66-67
+            sums[VS_Y1G] += vmask * ((AG - bn * G1) * im);
+            sums[VS_SGX] += vmask * (GXA - abn * GX);                                    // sum_k grad T_k * (B*y1+)_k
+            sums[VS_SGY] += vmask * (GYA - abn * GY);
+            wave_lds_sync();
+        }
+    }
+    {
+        double *st = stage_all + wave * CP_NSCAL;
+#pragma unroll
+        for (int a = 0; a < CP_NSUM; ++a) {
+            const double v = wave_sum(sums[a]);
+            if (lane == 0) st[a] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < CP_NMAX; ++a) {
+            const double v = wave_max(maxs[a]);
+            if (lane == 0) st[CP_NSUM + a] = v;
+        }
+        __syncthreads();
+        if (tid < CP_NSCAL) {
+            const bool is_max = tid >= CP_NSUM;
+            double v = stage_all[tid];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) {
+                const double o = stage_all[w * CP_NSCAL + tid];
+                v = is_max ? fmax(v, o) : v + o;
+            }
+            part[(size_t)blockIdx.x * CP_PSTRIDE + tid] = v;
+        }
+    }
+}
+
 // lazy state from a plain y1 (abar = mean_k y1_k, beta = 0) and back (y1_k = alpha_k - beta); lz = [abar field | beta field]
 __global__ __launch_bounds__(CP_BLOCK) void k_var_lazy_init(MfParams P, const double *__restrict__ p, double *__restrict__ lz) {
     for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
@@ -261,6 +418,7 @@ struct VarEFusedArgs {
     int nblk;
     int n;               // completes primal row n and dual row n, starts dual row n+1; start = 1: only the last (after dual step 1)
     int start, check_stop;
+    int reg;             // 1: variance-curvature: F2, F2* and the stop rule belong to k_var_curv_fin, which runs after k_curv_y2
     double tol, mu1, mu2, tau, Ntot;
 };
 
@@ -275,8 +433,8 @@ __global__ __launch_bounds__(256) void k_var_efused(VarEFusedArgs A, const doubl
     if (!A.start) {
         double *hp = hist_p + (size_t)n * CP_HCOLS_VAR, *hd = hist_d + (size_t)n * CP_HCOLS_VAR;
         const double F1 = A.mu1 * 0.5 * sc[DS_F1], F2 = A.mu2 * sc[DS_F2];           // NNE/SSD.m:48, norm21.m:56
-        hp[1] = F1; hp[2] = F2; hp[3] = 0.0;
-        hp[0] = hp[3] + (F1 + F2);                                                   // chambolle_pock.m:170-171
+        hp[1] = F1; hp[3] = 0.0;
+        if (A.reg == 0) { hp[2] = F2; hp[0] = hp[3] + (F1 + F2); }                   // chambolle_pock.m:170-171
         hp[4] = 0.0;
         hp[5] = fmax(fabs(sc[DS_UX] / A.Ntot), fabs(sc[DS_UY] / A.Ntot));            // mean_zero_indicator.m:65
         const double mw = sc[PS_WX] / A.Ntot;                                        // x-mean used for both (:78,:81)
@@ -287,11 +445,51 @@ __global__ __launch_bounds__(256) void k_var_efused(VarEFusedArgs A, const doubl
         hd[0] = -(hd[3] + (hd[1] + hd[2]));                                          // chambolle_pock.m:175-176
     }
     hd1[1] = A.mu1 * (0.5 * sc[VS_Y1SQ] + sc[VS_Y1G]);                               // NNE/SSD.m:66-67
-    hd1[2] = 0.0;                                                                    // norm21.m:80
-    hd1[4] = (sc[DM_S1] > A.mu2) ? sc[DM_S1] - A.mu2 : 0.0;                          // norm21.m:81-88
-    ctrl->cn[0] = sc[DS_UX] / A.Ntot - A.tau * (sc[VS_SGX] / A.Ntot);
-    ctrl->cn[1] = sc[DS_UY] / A.Ntot - A.tau * (sc[VS_SGY] / A.Ntot);
-    if (!A.start && A.check_stop && n >= 4) {                                        // chambolle_pock.m:142-153
+    if (A.reg == 0) {
+        hd1[2] = 0.0;                                                                // norm21.m:80
+        hd1[4] = (sc[DM_S1] > A.mu2) ? sc[DM_S1] - A.mu2 : 0.0;                      // norm21.m:81-88
+        ctrl->cn[0] = sc[DS_UX] / A.Ntot - A.tau * (sc[VS_SGX] / A.Ntot);
+        ctrl->cn[1] = sc[DS_UY] / A.Ntot - A.tau * (sc[VS_SGY] / A.Ntot);
+    } else {
+        hd1[4] = 0.0;                                                                // NNE/SSD.m: no constraint
+        if (A.start) {   // after k_var_dual<0, 1>: F2*(y2_1) and the boundary term of mean(Lap y2_1) come with the same partials
+            hd1[2] = A.mu2 * (0.5 * sc[DS_F2S]);                                     // NNE/SSD.m:66-67 (g = 0)
+            ctrl->cn[0] = sc[DS_UX] / A.Ntot - A.tau * (sc[VSC_SGX] / A.Ntot) - A.tau * (sc[DS_BSX] / A.Ntot);
+            ctrl->cn[1] = sc[DS_UY] / A.Ntot - A.tau * (sc[VS_SGY] / A.Ntot) - A.tau * (sc[DS_BSY] / A.Ntot);
+        } else {         // after k_var_lazy_curv: k_var_curv_fin adds the boundary term of y2_{n+1}
+            ctrl->cn[0] = sc[DS_UX] / A.Ntot - A.tau * (sc[VS_SGX] / A.Ntot);
+            ctrl->cn[1] = sc[DS_UY] / A.Ntot - A.tau * (sc[VS_SGY] / A.Ntot);
+        }
+    }
+    if (!A.start && A.check_stop && n >= 4 && A.reg == 0) {                          // chambolle_pock.m:142-153
+        bool ok = true;
+        for (int r = n - 4; r <= n; ++r) {
+            const double *p_ = hist_p + (size_t)r * CP_HCOLS_VAR, *d_ = hist_d + (size_t)r * CP_HCOLS_VAR;
+            const double gap = fabs((p_[0] - d_[0]) / d_[0]);
+            if (!(gap <= A.tol) || !(p_[4] <= A.tol) || !(p_[5] <= A.tol) || !(d_[4] <= A.tol) || !(d_[5] <= A.tol))
+                ok = false;
+        }
+        if (ok) { ctrl->stop = 1; ctrl->stop_iter = n; }
+    }
+}
+
+// after k_curv_y2(n) of the variance-curvature model: F2(A x_n) completes primal row n, F2*(y2_{n+1}) goes into dual row n+1,
+// the boundary term of the mean of the next un-projected u, the stop rule for i = n (cf. k_curv_fin)
+__global__ __launch_bounds__(256) void k_var_curv_fin(CurvFinArgs A, const double *__restrict__ part, CpCtrl *ctrl,
+                                                      double *hist_p, double *hist_d) {
+    __shared__ double sc[CP_NSCAL], stage[256];
+    if (ctrl->stop) return;
+    reduce_scalars(part, A.nblk, sc, stage);
+    if (threadIdx.x != 0) return;
+    const int n = A.n;
+    double *hp = hist_p + (size_t)n * CP_HCOLS_VAR, *hd1 = hist_d + (size_t)(n + 1) * CP_HCOLS_VAR;
+    const double F2 = A.mu2 * 0.5 * sc[DS_F2];                                       // NNE/SSD.m:48 (g = 0)
+    hp[2] = F2;
+    hp[0] = hp[3] + (hp[1] + F2);                                                    // chambolle_pock.m:170-171
+    hd1[2] = A.mu2 * (0.5 * sc[DS_F2S]);                                             // NNE/SSD.m:66-67 (g = 0)
+    ctrl->cn[0] -= A.tau * (sc[DS_BSX] / A.Ntot);                                    // - tau * mean(Lap y2_{n+1}), zero for neumann rows
+    ctrl->cn[1] -= A.tau * (sc[DS_BSY] / A.Ntot);
+    if (A.check_stop && n >= 4) {                                                    // chambolle_pock.m:142-153
         bool ok = true;
         for (int r = n - 4; r <= n; ++r) {
             const double *p_ = hist_p + (size_t)r * CP_HCOLS_VAR, *d_ = hist_d + (size_t)r * CP_HCOLS_VAR;

@@ -38,18 +38,18 @@ if "c5" in which:
         eng = E.Engine(E.MODEL_TV_L2_REG, m, n, lam=50.0, batch=B, flags=flags)
         eng.set_images(T, R); eng.set_primal(np.zeros(2*m*n*B)); eng.linearize()
         tau = 4.0; run(f"C5 TV-L2 256 x 512^2 {tag}", eng, 1.0, tau, (1 - 1e-4) / (8 * tau), 100, 23 * esz * m * n * B); eng.close()
-for tag, model, el, mu in (("c4", E.MODEL_MF_NN_CURV, 31, 20.0), ("var", E.MODEL_VAR_TV, 28, 0.1)):
+for tag, model, el, mu in (("c4", E.MODEL_MF_NN_CURV, 31, 20.0), ("var", E.MODEL_VAR_TV, 28, 0.1), ("varc", E.MODEL_VAR_CURV, 22, 5.0)):
     if tag not in which: continue
     m = n = 4096; k = 16
     dev = torch.device("cuda", 0)
     imgs = synth.dynamic_test_image(m, n, k, device=dev).transpose(1, 2).contiguous().cpu().numpy().reshape(-1)
     u0 = synth.smooth_displacement(m, n, k, amp=2.0, device=dev).cpu().numpy().reshape(-1)
     torch.cuda.empty_cache()
-    eng = E.Engine(model, m, n, k=k, bc="dirichlet" if tag == "c4" else "neumann", omega=[0.0, float(m), 0.0, float(n)], mu=mu)
+    eng = E.Engine(model, m, n, k=k, bc="dirichlet" if tag in ("c4", "varc") else "neumann", omega=[0.0, float(m), 0.0, float(n)], mu=mu)
     eng.set_images(imgs)
     eng.set_primal(np.concatenate([u0, np.zeros(k*m*n)]) if tag == "c4" else u0); eng.linearize()
     if tag == "c4": eng.set_nu(30.0)
-    run(("C4 NN-curvature" if tag == "c4" else "var-TV") + " 4096^2 x 16", eng, 1.0, 0.1, 0.1, 20, el * 8.0 * k * m * n); eng.close()
+    run({"c4": "C4 NN-curvature", "var": "var-TV", "varc": "var-curvature"}[tag] + " 4096^2 x 16", eng, 1.0, 0.1, 0.1, 20, el * 8.0 * k * m * n); eng.close()
 if "c1" in which:
     # C1: TV-L1 denoising of Data/rect1.png (fixture copy) with the committed salt & pepper mask, PDO/test_TV_L1_denoising.m
     from ma_amd import drivers as D

@@ -191,3 +191,49 @@ def test_var_tv_lazy_state_over_a_long_run(monkeypatch):
     monkeypatch.delenv("CP_TUNE_VAR_SPLIT")
     xl2, yl2, _, _ = run(E.FLAG_VAR_SSD_SWAP)
     assert _rel(xl2, xs2) < 1e-11 and _rel(yl2, ys2) < 1e-11
+
+
+@pytest.mark.parametrize("bc", ["dirichlet", "neumann"])
+def test_var_curvature_two_pass_path_over_a_long_run(monkeypatch, bc):
+    """k_var_lazy_curv + k_curv_y2 + k_var_curv_fin (cp_var_fused.cuh) against the oracle and the split passes: 250 iterations,
+    dual start not mean-free over the images; dirichlet rows exercise the boundary term of the mean known in advance, the
+    stop rule fires at the same iteration"""
+    from ma_amd import engine as E, synth
+    from oracle import drivers as od, prox as px
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    m, n, k, mu = 37, 44, 5, 5.0
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    u0 = synth.smooth_displacement(m, n, k, amp=1.5).numpy().reshape(k, 2, n * m)
+    u0_ref = np.transpose(u0, (2, 1, 0))
+    omega, h = [0.0, float(m), 0.0, float(n)], (1.0, 1.0)
+    A, b, T_u, gs = od.var_problem([imgs[i] for i in range(k)], u0_ref, h, omega, "curvature", bc)
+    tau = sigma = 0.1
+    rng = np.random.default_rng(5)
+    x0 = u0.reshape(-1)
+    y0 = 0.05 * rng.standard_normal(3 * k * m * n) + 0.02
+    iters, tol = 250, 2e-2
+    Fh = lambda y, c, nargout: od.var_F(y, -b, k, h, mu, sigma, c, nargout, "curvature")
+    Gh = lambda x, c, nargout: px.mean_zero_indicator(x, (m, n, k), c, nargout)
+    xr, yr, phr, dhr = cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, sigma, iters, tol)
+
+    def run():
+        eng = E.Engine(E.MODEL_VAR_CURV, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu)
+        eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+        eng.set_primal(x0)
+        eng.linearize()
+        eng.set_dual(y0)
+        eng.solve(1.0, tau, sigma, iters, tol)
+        out = (eng.primal(), eng.dual()) + tuple(eng.history())
+        eng.close()
+        return out
+
+    xl, yl, phl, dhl = run()
+    assert phl.shape == phr.shape                                  # same stopping iteration
+    assert _rel(xl, xr) < 1e-9 and _rel(yl, yr) < 1e-9
+    np.testing.assert_allclose(phl, phr, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(dhl, dhr, rtol=1e-8, atol=1e-10)
+    monkeypatch.setenv("CP_TUNE_VAR_SPLIT", "1")
+    xs, ys, phs, dhs = run()
+    assert phs.shape == phl.shape and _rel(xl, xs) < 1e-11 and _rel(yl, ys) < 1e-11
+    np.testing.assert_allclose(phl, phs, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(dhl, dhs, rtol=1e-10, atol=1e-12)
