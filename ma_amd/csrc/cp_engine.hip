@@ -288,6 +288,10 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
     // the field kernels address a field with 32-bit byte offsets (ldo / sto, cp_device.cuh) and count pixels in int
     if ((long long)d.m * ((long long)d.n + 2) * (long long)sizeof(double) >= (1LL << 32))
         CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported a field of %d x %d doubles reaches 4 GiB (32-bit offsets inside a field)", d.m, d.n);
+    // the buffer-addressed kernels of the multi-image models reach the second field of a pair through the descriptor's
+    // uniform offset: lane offset + field size stays below 2^32 (whichever way the range check counts that offset)
+    if (mf && (long long)d.m * ((long long)d.n + 2) * (long long)sizeof(double) >= (1LL << 31))
+        CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported a field of %d x %d doubles reaches 2 GiB (multi-image models)", d.m, d.n);
     cp_engine *h = new cp_engine();
     h->d = d;
     if (h->d.batch < 1) h->d.batch = 1;
@@ -362,9 +366,10 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         // 8 adjacent columns per workgroup with the LDS hand-over between neighbouring waves (cp_mfnn_fused.cuh) where that
         // instantiation exists (K = 16, neumann / dirichlet rows) and the problem still gives every CU a workgroup
         h->fused_waves = 8;
-        if (const char *ev = getenv("CP_TUNE_FUSED_WAVES")) { if (atoi(ev) == 4) h->fused_waves = CP_WAVES; }
+        bool force8 = false;   // CP_TUNE_FUSED_WAVES=8: also for small problems and fp32 storage (tests of the hand-over at small sizes)
+        if (const char *ev = getenv("CP_TUNE_FUSED_WAVES")) { if (atoi(ev) == 4) h->fused_waves = CP_WAVES; force8 = atoi(ev) == 8; }
         if (!(mf && !var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (h->d.flags & CP_FLAG_MFNN_NORM21) || h->fused_cw != 1 ||
-            h->K != CP_KMAX || fused2_tasks(h->m, h->nl, 1, 8) < 256 || (h->d.flags & CP_FLAG_FP32))   // fp32 storage: 5.5 vs 6.9 ms with 4 waves
+            h->K != CP_KMAX || (!force8 && (fused2_tasks(h->m, h->nl, 1, 8) < 256 || (h->d.flags & CP_FLAG_FP32))))   // fp32 storage: 5.5 vs 6.9 ms with 4 waves
             h->fused_waves = CP_WAVES;
         h->nblk_tv = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw, h->fused_waves) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         h->curv_fused = mf && !var && h->reg == 1;

@@ -240,3 +240,39 @@ def test_long_run_against_c_restatement():
     np.testing.assert_allclose(ph[:, 0], phr[:, 0], rtol=1e-10)
     np.testing.assert_allclose(dh[:, 0], dhr[:, 0], rtol=1e-10)
     assert _rel(x, xr) < TOL and _rel(y, yr) < TOL
+
+
+@pytest.mark.parametrize("m,n,fp32", [(70, 37, False), (33, 8, False), (130, 21, False), (64, 16, True)])
+def test_fused_tv_wave_hand_over_equals_the_recomputation(monkeypatch, m, n, fp32):
+    """k_mf_fused_tv with 8 waves per workgroup hands the own-pixel result of column j+1 to the wave of column j through LDS
+    (cp_mfnn_fused.cuh: hs_give / hs_take) instead of recomputing it from y_n: the same iterates and histories as the 4-wave
+    instantiation, which recomputes (the handed-over numbers are bitwise the recomputed ones; the partial sums are grouped by
+    workgroup, so means and Gram matrices differ in the last bit: 1e-13), at sizes with partial segments, column groups that end inside a workgroup
+    and a single column group; 60 iterations with the stop rule armed"""
+    from ma_amd import engine as E, synth
+    k = 16
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    u0 = synth.smooth_displacement(m, n, k, amp=1.0).numpy().reshape(-1)
+    omega = [0.0, float(m), 0.0, float(n)]
+
+    def run(waves):
+        monkeypatch.setenv("CP_TUNE_FUSED_WAVES", waves)
+        eng = E.Engine(E.MODEL_MF_NN_TV, m, n, k=k, bc="neumann", h=(1.0, 1.0), omega=omega, mu=0.2, flags=E.FLAG_FP32 if fp32 else 0)
+        eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+        eng.set_primal(np.concatenate([u0, np.zeros(k * m * n)]))
+        eng.linearize()
+        eng.set_nu(0.9 * float(np.sum(eng.singular_values(0))))
+        est, _ = eng.norm_estimate()
+        tau = float(np.sqrt(0.99 / est ** 2))
+        res = eng.solve(1.0, tau, tau, 60, 1e-2)
+        out = (eng.primal(), eng.dual()) + tuple(eng.history()) + (res.iterations,)
+        eng.close()
+        return out
+
+    a, b = run("8"), run("4")
+    assert a[4] == b[4]
+    tol = 1e-6 if fp32 else 1e-13
+    for u, v in zip(a[:2], b[:2]):
+        assert np.linalg.norm(u - v) <= tol * np.linalg.norm(v)
+    for u, v in zip(a[2:4], b[2:4]):
+        np.testing.assert_allclose(u, v, rtol=1e3 * tol, atol=10 * tol)

@@ -21,6 +21,19 @@ def test_slabs_match_single_gpu(world, k, reg, bc):
     assert r.returncode == 0
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_slabs_with_the_wave_hand_over_kernel(world):
+    """the 8-columns-per-workgroup instantiation of k_mf_fused_tv (LDS hand-over between neighbouring waves) is the default
+    only for large problems; forced here (CP_TUNE_FUSED_WAVES=8) so that its slab edges -- the last owned column takes its
+    (i, j+1) neighbour from the halo column, column groups that end inside a workgroup -- meet the single-handle result"""
+    env = dict(os.environ, SLAB_K="16", SLAB_REG="tv", SLAB_BC="neumann", MASTER_ADDR="127.0.0.1", CP_TUNE_FUSED_WAVES="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29440 + world), os.path.join(ROOT, "tests", "slab_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0
+
+
 def test_rccl_backend_single_rank():
     """the multi-GPU driver over the RCCL backend (device-tensor all-gather, torch stream hand-over) on one rank"""
     env = dict(os.environ, CP_FORCE_SLAB_PATH="1", MASTER_ADDR="127.0.0.1")
