@@ -404,10 +404,13 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
                                h->svout + 16 + 256);
         } else {
             if (h->fp32) HIPCHK(hipMalloc(&h->stage, sizeof(double) * h->npix));
-            // marching kernel when it yields enough waves to fill the chip (8 per SIMD slot would be 8192): strips of
-            // 16 columns, else 8; small problems stay on k_pw_fused (one 256-pixel chunk per workgroup)
+            // marching kernel when it yields enough waves to fill the chip (8 per SIMD slot would be 8192); small problems stay
+            // on k_pw_fused (one 256-pixel chunk per workgroup). Strip width, measured on 256 x 512^2 (ms per iteration of the
+            // batch, fp64 / fp32 storage): 16 columns 2.04 / 1.03, 8: 1.94 / 0.99, 6: 1.79 / -, 4: 1.81 / 1.08, 3: 1.84, 2: 1.98
+            // -- narrow strips recompute more ((C+1)/C evaluations per pixel) but start more waves, and a strip of 8 columns of
+            // 512 rows puts the waves 32 KB apart; 2048^2: 4, 6 and 8 alike (0.135), 16: 0.143
             h->pw_groups = (h->m + 62) / 63;
-            for (int strip : {16, 8}) {
+            for (int strip : {h->fp32 ? 8 : 6, 4}) {
                 const long long waves = (long long)h->pw_groups * ((h->nl + strip - 1) / strip) * h->batch;
                 if (waves >= 8192) { h->pw_strip = strip; break; }
             }
