@@ -362,6 +362,15 @@ def main():
                          "algorithmic_GB_per_launch": dual_bytes / 1e9,
                          "hbm_achieved": (traffic / dual_avg_s) if (traffic and dual_avg_s > 0) else None,
                          "hbm_frac": (traffic / dual_avg_s / HBM_PEAK_GBS) if (traffic and dual_avg_s > 0) else None,
+                         # the Gram step on the matrix cores (v_mfma_f64_16x16x4_f64): two 16 x 16 Gram matrices over the
+                         # pixels of the slab = 2 * 2 * 256 flop per pixel inside the dominant kernel (rocprofv3:
+                         # SQ_INSTS_VALU_MFMA_MOPS_F64 * 512 in profiles/); 78.6 TFLOP/s = AMD's data-sheet fp64 matrix peak.
+                         # The kernel is HBM-bound by design: the matrix cores idle, they are used because the contraction
+                         # costs nothing there.
+                         "gram_mfma": {"flop_per_launch": 4.0 * 256 * m * part.nl,
+                                       "achieved_TFLOPs": (4.0 * 256 * m * part.nl / dual_avg_s / 1e12) if dual_avg_s > 0 else None,
+                                       "peak_TFLOPs": 78.6,
+                                       "frac": (4.0 * 256 * m * part.nl / dual_avg_s / 1e12 / 78.6) if dual_avg_s > 0 else None},
                          "measured_copy_GBps": copy_gbs,
                          "hbm_frac_of_measured_copy": (traffic / dual_avg_s / max(copy_gbs.values())) if (traffic and dual_avg_s > 0 and copy_gbs) else None},
         }
