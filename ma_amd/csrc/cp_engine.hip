@@ -63,7 +63,7 @@ struct PassTimer {
 struct cp_engine {
     cp_problem_desc d;
     bool mf = false;     // multi-image model (mf_nn or var): K images, CpCtrl, MfParams
-    bool fp32 = false;   // CP_FLAG_FP32 (pairwise, mf_nn): fields stored as float inside the double-sized allocations
+    bool fp32 = false;   // CP_FLAG_FP32: fields stored as float inside the double-sized allocations
     double *vwarm = nullptr;   // NN-TV: eigenvector bases of the previous iteration (2 x 256), warm start of k_mf_efused
     double *stage = nullptr;   // fp32 mode: one field of doubles for host <-> device conversion
     bool var = false;    // variance model (no L block, no nuclear norm): cp_var.cuh
@@ -301,10 +301,6 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         h->d.omega[3] = h->d.n_global * d.h[1];
     }
     if (pw && (h->d.n_global != d.n)) { delete h; CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported slabs for pairwise models"); }
-    if ((d.flags & CP_FLAG_FP32) && var) {
-        delete h;
-        CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported the fp32 mode covers the pairwise and mf_nn models");
-    }
     h->fp32 = (d.flags & CP_FLAG_FP32) != 0;
     h->mf = mf;
     h->var = var;
@@ -516,7 +512,8 @@ extern "C" int cp_linearize(cp_handle h, const double *u0) {
         else
             hipLaunchKernelGGL((k_mf_warp<double>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, W, h->img, xsrc, h->Tu, h->g, h->b);
         if (h->var)   // b <- B*b, NNE/var_tv_registration_no_ref_ml.m:153-154
-            hipLaunchKernelGGL(k_var_center_b, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, mf_params(h, 1.0, 1.0, 1.0), h->b);
+            { if (h->fp32) hipLaunchKernelGGL(k_var_center_b<float>, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, mf_params(h, 1.0, 1.0, 1.0), (float *)h->b);
+              else hipLaunchKernelGGL(k_var_center_b<double>, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, mf_params(h, 1.0, 1.0, 1.0), h->b); }
     } else {
         PwWarpParams W;
         W.m = h->m; W.n = h->nl; W.npix = h->npix; W.fs = h->fs; W.nxf = h->nxf;
@@ -557,7 +554,8 @@ extern "C" int cp_set_linearization(cp_handle h, const double *T_u, const double
     CPCHK(upload_fields(h, h->g, grad, 2 * h->K * h->batch));
     CPCHK(upload_fields(h, h->b, b, h->K * h->batch));
     if (h->var) {
-        hipLaunchKernelGGL(k_var_center_b, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, mf_params(h, 1.0, 1.0, 1.0), h->b);
+        { if (h->fp32) hipLaunchKernelGGL(k_var_center_b<float>, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, mf_params(h, 1.0, 1.0, 1.0), (float *)h->b);
+              else hipLaunchKernelGGL(k_var_center_b<double>, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, mf_params(h, 1.0, 1.0, 1.0), h->b); }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -604,13 +602,19 @@ static void launch_mf_applyAT(cp_engine *h, const MfParams &P, const double *y, 
     }
 }
 static void launch_any_applyA(cp_engine *h, const MfParams &P, const double *x, double scale, double *y) {
-    if (h->var && h->reg == 0) hipLaunchKernelGGL((k_var_applyA<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
-    else if (h->var) hipLaunchKernelGGL((k_var_applyA<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
+    if (h->var && h->fp32) {
+        if (h->reg == 0) hipLaunchKernelGGL((k_var_applyA<float, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
+        else hipLaunchKernelGGL((k_var_applyA<float, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
+    } else if (h->var && h->reg == 0) hipLaunchKernelGGL((k_var_applyA<double, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
+    else if (h->var) hipLaunchKernelGGL((k_var_applyA<double, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
     else launch_mf_applyA(h, P, x, scale, y);
 }
 static void launch_any_applyAT(cp_engine *h, const MfParams &P, const double *y, double *xo) {
-    if (h->var && h->reg == 0) hipLaunchKernelGGL((k_var_applyAT<0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
-    else if (h->var) hipLaunchKernelGGL((k_var_applyAT<1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
+    if (h->var && h->fp32) {
+        if (h->reg == 0) hipLaunchKernelGGL((k_var_applyAT<float, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
+        else hipLaunchKernelGGL((k_var_applyAT<float, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
+    } else if (h->var && h->reg == 0) hipLaunchKernelGGL((k_var_applyAT<double, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
+    else if (h->var) hipLaunchKernelGGL((k_var_applyAT<double, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
     else launch_mf_applyAT(h, P, y, xo);
 }
 // the power iteration's vectors move between host and device as doubles in every mode
@@ -997,24 +1001,35 @@ static int mf_end(cp_engine *h, const MfParams &P, int iterations) {
 }
 
 // ---- variance models (cp_var.cuh) -----------------------------------------------------------------------------
+template <typename S, int MODE>
+static void launch_var_dual_t(cp_engine *h, const MfParams &P, const double *xc, const double *xo, const double *pin,
+                              double *pout, int cc, int co) {
+    if (h->reg == 0)
+        hipLaunchKernelGGL((k_var_dual<S, MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xc, (const S *)xo,
+                           (const S *)pin, (S *)pout, (const S *)h->g, (const S *)h->b, (const CpCtrl *)h->ctrl, cc, co, h->part);
+    else
+        hipLaunchKernelGGL((k_var_dual<S, MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xc, (const S *)xo,
+                           (const S *)pin, (S *)pout, (const S *)h->g, (const S *)h->b, (const CpCtrl *)h->ctrl, cc, co, h->part);
+}
 template <int MODE>
 static void launch_var_dual(cp_engine *h, const MfParams &P, const double *xc, const double *xo, const double *pin,
                             double *pout, int cc, int co) {
+    if (h->fp32) launch_var_dual_t<float, MODE>(h, P, xc, xo, pin, pout, cc, co);
+    else launch_var_dual_t<double, MODE>(h, P, xc, xo, pin, pout, cc, co);
+}
+template <typename S, int MODE>
+static void launch_var_primal_t(cp_engine *h, const MfParams &P, const double *xc, double *xn, const double *p, int cc) {
     if (h->reg == 0)
-        hipLaunchKernelGGL((k_var_dual<MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout, h->g,
-                           h->b, (const CpCtrl *)h->ctrl, cc, co, h->part);
+        hipLaunchKernelGGL((k_var_primal<S, MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xc, (S *)xn,
+                           (const S *)p, (const S *)h->g, (const CpCtrl *)h->ctrl, cc, h->part);
     else
-        hipLaunchKernelGGL((k_var_dual<MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout, h->g,
-                           h->b, (const CpCtrl *)h->ctrl, cc, co, h->part);
+        hipLaunchKernelGGL((k_var_primal<S, MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xc, (S *)xn,
+                           (const S *)p, (const S *)h->g, (const CpCtrl *)h->ctrl, cc, h->part);
 }
 template <int MODE>
 static void launch_var_primal(cp_engine *h, const MfParams &P, const double *xc, double *xn, const double *p, int cc) {
-    if (h->reg == 0)
-        hipLaunchKernelGGL((k_var_primal<MODE, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g,
-                           (const CpCtrl *)h->ctrl, cc, h->part);
-    else
-        hipLaunchKernelGGL((k_var_primal<MODE, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g,
-                           (const CpCtrl *)h->ctrl, cc, h->part);
+    if (h->fp32) launch_var_primal_t<float, MODE>(h, P, xc, xn, p, cc);
+    else launch_var_primal_t<double, MODE>(h, P, xc, xn, p, cc);
 }
 static VarFinArgs var_fin_args(const cp_engine *h, const MfParams &P, int rp, int rd, int check, int update, int newbuf,
                                double tol) {
@@ -1059,24 +1074,33 @@ static int var_fused_start(cp_engine *h, const MfParams &P) {
     A.nblk = h->nblk; A.reg = h->reg;
     hipLaunchKernelGGL(k_var_efused, dim3(1), dim3(256), 0, h->stream, A, h->part, (CpCtrl *)h->ctrl, h->hist_p, h->hist_d);
     // y_1 = alpha_1 - beta_1 with beta_1 = 0, abar_1 = mean_k y1
-    hipLaunchKernelGGL(k_var_lazy_init, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (const double *)h->P[1], h->vlazy[1]);
+    if (h->fp32) hipLaunchKernelGGL(k_var_lazy_init<float>, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (const float *)h->P[1], h->vlazy[1]);
+    else hipLaunchKernelGGL(k_var_lazy_init<double>, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (const double *)h->P[1], h->vlazy[1]);
     h->lazy_live = true;
     HIPCHK(hipGetLastError());
     return CP_OK;
 }
-static void launch_var_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn) {
-    const bool lin = (h->d.bc == CP_BC_LINEAR);
+template <typename S>
+static void launch_var_fused_t(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn) {
     const int cur = (pc == h->P[1]) ? 1 : 0;
+    const S *xps = (const S *)xp, *pcs = (const S *)pc, *gs = (const S *)h->g, *bs = (const S *)h->b;
+    const double *lzi = h->vlazy[cur];
+    double *lzo = h->vlazy[cur ^ 1];
     if (h->reg != 0) {
         const bool neu = (h->d.bc == CP_BC_NEUMANN);
-        hipLaunchKernelGGL(neu ? k_var_lazy_curv<true> : k_var_lazy_curv<false>, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, xp,
-                           xc, pc, pn, (const double *)h->g, (const double *)h->b, (const double *)h->vlazy[cur], h->vlazy[cur ^ 1],
+        auto kern = neu ? k_var_lazy_curv<S, true> : k_var_lazy_curv<S, false>;
+        hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, xps, (S *)xc, pcs, (S *)pn, gs, bs, lzi, lzo,
                            (const CpCtrl *)h->ctrl, h->part);
         return;
     }
-    hipLaunchKernelGGL(lin ? k_var_lazy_tv<true> : k_var_lazy_tv<false>, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, xp, xc,
-                       pc, pn, (const double *)h->g, (const double *)h->b, (const double *)h->vlazy[cur], h->vlazy[cur ^ 1],
+    const bool lin = (h->d.bc == CP_BC_LINEAR);
+    auto kern = lin ? k_var_lazy_tv<S, true> : k_var_lazy_tv<S, false>;
+    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, xps, (S *)xc, pcs, (S *)pn, gs, bs, lzi, lzo,
                        (const CpCtrl *)h->ctrl, h->part);
+}
+static void launch_var_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn) {
+    if (h->fp32) launch_var_fused_t<float>(h, P, xp, xc, pc, pn);
+    else launch_var_fused_t<double>(h, P, xp, xc, pc, pn);
 }
 static int var_fused_iterations(cp_engine *h, const MfParams &P, int n0, int count, int check, double tol) {
     for (int n = n0 + 1; n <= n0 + count; ++n) {
@@ -1092,7 +1116,8 @@ static int var_fused_iterations(cp_engine *h, const MfParams &P, int n0, int cou
         if (h->time_all) CPCHK(timer_end(h, T_EIG));
         if (h->reg != 0) {   // variance-curvature: y2_{n+1} (the kernel of the NN-curvature model), then F2 / F2* / boundary term / stop rule
             CPCHK(timer_begin(h, T_PRIMAL));
-            launch_curv_y2_t<double>(h, P, h->X[cur], h->X[prv], h->P[cur], h->P[nxt]);
+            if (h->fp32) launch_curv_y2_t<float>(h, P, h->X[cur], h->X[prv], h->P[cur], h->P[nxt]);
+            else launch_curv_y2_t<double>(h, P, h->X[cur], h->X[prv], h->P[cur], h->P[nxt]);
             CPCHK(timer_end(h, T_PRIMAL));
             CurvFinArgs F;
             F.n = n; F.check_stop = check; F.tol = tol; F.mu2 = P.mu2; F.tau = P.tau; F.Ntot = P.Ntot;
@@ -1108,11 +1133,16 @@ static int var_fused_iterations(cp_engine *h, const MfParams &P, int n0, int cou
 static int var_end(cp_engine *h, const MfParams &P, int iterations) {
     const int fb = iterations & 1;
     if (h->lazy_live) {   // y1 = alpha - beta in place, before the copy into the canonical buffers
-        hipLaunchKernelGGL(k_var_lazy_finish, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->P[fb], (const double *)h->vlazy[fb]);
+        if (h->fp32) hipLaunchKernelGGL(k_var_lazy_finish<float>, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (float *)h->P[fb], (const double *)h->vlazy[fb]);
+        else hipLaunchKernelGGL(k_var_lazy_finish<double>, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->P[fb], (const double *)h->vlazy[fb]);
         h->lazy_live = false;
     }
-    hipLaunchKernelGGL(k_var_materialize, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->npf, h->X[fb], h->X[0], h->P[fb],
-                       h->P[0], (const CpCtrl *)h->ctrl, fb);
+    if (h->fp32)
+        hipLaunchKernelGGL(k_var_materialize<float>, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->npf, (const float *)h->X[fb],
+                           (float *)h->X[0], (const float *)h->P[fb], (float *)h->P[0], (const CpCtrl *)h->ctrl, fb);
+    else
+        hipLaunchKernelGGL(k_var_materialize<double>, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->npf, (const double *)h->X[fb],
+                           h->X[0], (const double *)h->P[fb], h->P[0], (const CpCtrl *)h->ctrl, fb);
     hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1]);
     HIPCHK(hipGetLastError());
     return CP_OK;

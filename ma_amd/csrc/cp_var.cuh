@@ -58,22 +58,24 @@ __device__ __forceinline__ void reduce_scalars(const double *__restrict__ part, 
 }
 
 // b <- B*b (centering over the images, NNE/var_tv...:153-154)
-__global__ __launch_bounds__(CP_BLOCK) void k_var_center_b(MfParams P, double *__restrict__ b) {
+template <typename S>
+__global__ __launch_bounds__(CP_BLOCK) void k_var_center_b(MfParams P, S *__restrict__ b) {
     for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
         const int e = q + P.m;
         double s = 0.0;
-        for (int k = 0; k < P.K; ++k) s += b[(size_t)k * P.fs + e];
+        for (int k = 0; k < P.K; ++k) s += (double)b[(size_t)k * P.fs + e];
         const double mean = s * P.invK;
-        for (int k = 0; k < P.K; ++k) b[(size_t)k * P.fs + e] -= mean;
+        for (int k = 0; k < P.K; ++k) b[(size_t)k * P.fs + e] = (S)((double)b[(size_t)k * P.fs + e] - mean);
     }
 }
 
 // MODE 0: update (writes pout); MODE 1: monitor only (y_new := y_in). REG 0: TV, REG 1: curvature.
-template <int MODE, int REG>
-__global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double *__restrict__ xc,
-                                                       const double *__restrict__ xo,
-                                                       const double *__restrict__ pin, double *__restrict__ pout,
-                                                       const double *__restrict__ g, const double *__restrict__ bbar,
+// S = storage type of the fields (double, or float with CP_FLAG_FP32): values are computed in double and rounded when stored
+template <typename S, int MODE, int REG>
+__global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const S *__restrict__ xc,
+                                                       const S *__restrict__ xo,
+                                                       const S *__restrict__ pin, S *__restrict__ pout,
+                                                       const S *__restrict__ g, const S *__restrict__ bbar,
                                                        const CpCtrl *__restrict__ ctrl, int cbuf_c, int cbuf_o,
                                                        double *__restrict__ part) {
     __shared__ double red[CP_WAVES * CP_NSCAL];
@@ -112,8 +114,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
         double sy = 0.0, sgx = 0.0, sgy = 0.0, sgxy = 0.0, sgyy = 0.0;   // for the mean of the next un-projected u (cp_var_fused.cuh: k_var_lazy_tv continues from this dual step)
 
         for (int k = 0; k < K; ++k) {
-            const double *uxc = xc + (size_t)(2 * k) * fs + e, *uyc = xc + (size_t)(2 * k + 1) * fs + e;
-            const double *uxo = xo + (size_t)(2 * k) * fs + e, *uyo = xo + (size_t)(2 * k + 1) * fs + e;
+            const S *uxc = xc + (size_t)(2 * k) * fs + e, *uyc = xc + (size_t)(2 * k + 1) * fs + e;
+            const S *uxo = xo + (size_t)(2 * k) * fs + e, *uyo = xo + (size_t)(2 * k + 1) * fs + e;
             const double ux = uxc[0] - ccx, uy = uyc[0] - ccy;
             const double uxb = ux + theta * (ux - (uxo[0] - cox)), uyb = uy + theta * (uy - (uyo[0] - coy));
             const double gx = g[(size_t)(2 * k) * fs + e], gy = g[(size_t)(2 * k + 1) * fs + e];
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
                     const double lt = P.mu1 * inv_sigma;
                     y1n = yt - sigma * ((yt * inv_sigma + lt * gg) / (1.0 + lt));
                 }
-                pout[(size_t)k * fs + e] = y1n;
+                y1n = rnd<S>(y1n);                                    // what the store keeps
+                pout[(size_t)k * fs + e] = (S)y1n;
             } else {
                 y1n = y1;
             }
@@ -173,15 +176,15 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
                 const double e2 = fwd_diff(uyb, uybi, uybi, last_i, linear, P.inv_h1);
                 const double e3 = fwd_diff(uyb, uybj, uybj, last_j, linear, P.inv_h2);
                 sums[DS_F2] += sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);      // NNE/norm21.m:56
-                const double *y2 = pin + (size_t)(K + 4 * k) * fs + e;
+                const S *y2 = pin + (size_t)(K + 4 * k) * fs + e;
                 const double v0 = y2[0], v1 = y2[(size_t)fs], v2 = y2[2 * (size_t)fs], v3 = y2[3 * (size_t)fs];
                 double n0, n1, n2, n3;
                 if (MODE == 0) {
                     const double t0 = v0 + sigma * e0, t1 = v1 + sigma * e1, t2 = v2 + sigma * e2, t3 = v3 + sigma * e3;
                     const double nn = fmax(sqrt(t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3), P.mu2);   // NNE/norm21.m:70
-                    n0 = (P.mu2 * t0) / nn; n1 = (P.mu2 * t1) / nn; n2 = (P.mu2 * t2) / nn; n3 = (P.mu2 * t3) / nn;  // :71-72
-                    double *o2 = pout + (size_t)(K + 4 * k) * fs + e;
-                    o2[0] = n0; o2[(size_t)fs] = n1; o2[2 * (size_t)fs] = n2; o2[3 * (size_t)fs] = n3;
+                    n0 = rnd<S>((P.mu2 * t0) / nn); n1 = rnd<S>((P.mu2 * t1) / nn); n2 = rnd<S>((P.mu2 * t2) / nn); n3 = rnd<S>((P.mu2 * t3) / nn);  // :71-72
+                    S *o2 = pout + (size_t)(K + 4 * k) * fs + e;
+                    o2[0] = (S)n0; o2[(size_t)fs] = (S)n1; o2[2 * (size_t)fs] = (S)n2; o2[3 * (size_t)fs] = (S)n3;
                 } else {
                     n0 = v0; n1 = v1; n2 = v2; n3 = v3;
                 }
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
                 double lapc[2], lapb[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const double *pc = c ? uyc : uxc, *po = c ? uyo : uxo;
+                    const S *pc = c ? uyc : uxc, *po = c ? uyo : uxo;
                     const double oc = c ? ccy : ccx, oo = c ? coy : cox;
                     const double uc0 = c ? uy : ux, ub0 = c ? uyb : uxb;
                     double nb[4], nbb[4];
@@ -208,16 +211,16 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
                     lapb[c] = (nbb[0] + nbb[1] - 2.0 * ub0) * ih1 + (nbb[2] + nbb[3] - 2.0 * ub0) * ih2;
                 }
                 sums[DS_F2] += lapc[0] * lapc[0] + lapc[1] * lapc[1];            // NNE/SSD.m:48 (g = 0)
-                const double *y2 = pin + (size_t)(K + 2 * k) * fs + e;
+                const S *y2 = pin + (size_t)(K + 2 * k) * fs + e;
                 const double v0 = y2[0], v1 = y2[(size_t)fs];
                 double n0, n1;
                 if (MODE == 0) {
                     const double t0 = v0 + sigma * lapb[0], t1 = v1 + sigma * lapb[1];
                     const double den = 1.0 + P.mu2 * inv_sigma;
-                    n0 = t0 - sigma * ((t0 * inv_sigma) / den);
-                    n1 = t1 - sigma * ((t1 * inv_sigma) / den);
-                    double *o2 = pout + (size_t)(K + 2 * k) * fs + e;
-                    o2[0] = n0; o2[(size_t)fs] = n1;
+                    n0 = rnd<S>(t0 - sigma * ((t0 * inv_sigma) / den));
+                    n1 = rnd<S>(t1 - sigma * ((t1 * inv_sigma) / den));
+                    S *o2 = pout + (size_t)(K + 2 * k) * fs + e;
+                    o2[0] = (S)n0; o2[(size_t)fs] = (S)n1;
                 } else {
                     n0 = v0; n1 = v1;
                 }
@@ -245,10 +248,10 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_dual(MfParams P, const double 
     block_reduce_store<CP_NSUM, CP_NMAX>(sums, maxs, red, part + (size_t)blockIdx.x * CP_PSTRIDE);
 }
 
-template <int MODE, int REG>
-__global__ __launch_bounds__(CP_BLOCK) void k_var_primal(MfParams P, const double *__restrict__ xc,
-                                                         double *__restrict__ xn, const double *__restrict__ p,
-                                                         const double *__restrict__ g, const CpCtrl *__restrict__ ctrl,
+template <typename S, int MODE, int REG>
+__global__ __launch_bounds__(CP_BLOCK) void k_var_primal(MfParams P, const S *__restrict__ xc,
+                                                         S *__restrict__ xn, const S *__restrict__ p,
+                                                         const S *__restrict__ g, const CpCtrl *__restrict__ ctrl,
                                                          int cbuf_c, double *__restrict__ part) {
     __shared__ double red[CP_WAVES * CP_NSCAL];
     if (ctrl->stop) return;
@@ -276,11 +279,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_primal(MfParams P, const doubl
             const double gx = g[(size_t)(2 * k) * fs + e], gy = g[(size_t)(2 * k + 1) * fs + e];
             double vux, vuy;
             if (REG == 0) {
-                const double *y2 = p + (size_t)(K + 4 * k) * fs + e;
+                const S *y2 = p + (size_t)(K + 4 * k) * fs + e;
                 double adj[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const double *f = y2 + (size_t)c * fs;
+                    const S *f = y2 + (size_t)c * fs;
                     const double wc = f[0];
                     if ((c & 1) == 0) {
                         const double wm = (i >= 1) ? f[-1] : 0.0;
@@ -296,11 +299,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_primal(MfParams P, const doubl
                 vuy = gy * yc + (adj[2] + adj[3]);
             } else {
                 const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
-                const double *y2 = p + (size_t)(K + 2 * k) * fs + e;
+                const S *y2 = p + (size_t)(K + 2 * k) * fs + e;
                 double lap[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const double *f = y2 + (size_t)c * fs;
+                    const S *f = y2 + (size_t)c * fs;
                     const double w0 = f[0];
                     const double a0 = (i > 0) ? f[-1] : (neumann ? w0 : 0.0);
                     const double a1 = (i < m - 1) ? f[1] : (neumann ? w0 : 0.0);
@@ -313,9 +316,9 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_primal(MfParams P, const doubl
             }
             const double ux = xc[(size_t)(2 * k) * fs + e] - ccx, uy = xc[(size_t)(2 * k + 1) * fs + e] - ccy;
             if (MODE == 0) {
-                const double ntx = ux - tau * vux, nty = uy - tau * vuy;    // mean subtracted lazily (c of xn)
-                xn[(size_t)(2 * k) * fs + e] = ntx;
-                xn[(size_t)(2 * k + 1) * fs + e] = nty;
+                const double ntx = rnd<S>(ux - tau * vux), nty = rnd<S>(uy - tau * vuy);    // mean subtracted lazily (c of xn)
+                xn[(size_t)(2 * k) * fs + e] = (S)ntx;
+                xn[(size_t)(2 * k + 1) * fs + e] = (S)nty;
                 sums[PS_UX] += ntx;
                 sums[PS_UY] += nty;
             }
@@ -387,16 +390,17 @@ __global__ __launch_bounds__(256) void k_var_fin_primal(VarFinArgs A, const doub
 }
 
 // canonical state: x - pending mean offsets into xd, dual copied if the buffers differ
-__global__ __launch_bounds__(CP_BLOCK) void k_var_materialize(MfParams P, int npf, const double *__restrict__ xs,
-                                                              double *__restrict__ xd, const double *__restrict__ ps,
-                                                              double *__restrict__ pd, const CpCtrl *__restrict__ ctrl,
+template <typename S>
+__global__ __launch_bounds__(CP_BLOCK) void k_var_materialize(MfParams P, int npf, const S *__restrict__ xs,
+                                                              S *__restrict__ xd, const S *__restrict__ ps,
+                                                              S *__restrict__ pd, const CpCtrl *__restrict__ ctrl,
                                                               int cbuf) {
     const double cx = ctrl->c[cbuf][0], cy = ctrl->c[cbuf][1];
     for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
         const int e = q + P.m;
         for (int k = 0; k < P.K; ++k) {
-            xd[(size_t)(2 * k) * P.fs + e] = xs[(size_t)(2 * k) * P.fs + e] - cx;
-            xd[(size_t)(2 * k + 1) * P.fs + e] = xs[(size_t)(2 * k + 1) * P.fs + e] - cy;
+            xd[(size_t)(2 * k) * P.fs + e] = (S)((double)xs[(size_t)(2 * k) * P.fs + e] - cx);
+            xd[(size_t)(2 * k + 1) * P.fs + e] = (S)((double)xs[(size_t)(2 * k + 1) * P.fs + e] - cy);
         }
         if (ps != pd)
             for (int f = 0; f < npf; ++f) pd[(size_t)f * P.fs + e] = ps[(size_t)f * P.fs + e];
@@ -404,9 +408,9 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_materialize(MfParams P, int np
 }
 
 // ---- power iteration of NNE/matrix_norm.m on A = [B*diag(grad T); D|Lap] -------------------------------------
-template <int REG>
+template <typename S, int REG>
 __global__ __launch_bounds__(CP_BLOCK) void k_var_applyA(MfParams P, const double *__restrict__ x, double scale,
-                                                         const double *__restrict__ g, double *__restrict__ y) {
+                                                         const S *__restrict__ g, double *__restrict__ y) {
     const int K = P.K, m = P.m, fs = P.fs;
     const bool linear = (P.bc == 1), neumann = (P.bc == 0);
     for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
@@ -448,9 +452,9 @@ __global__ __launch_bounds__(CP_BLOCK) void k_var_applyA(MfParams P, const doubl
     }
 }
 
-template <int REG>
+template <typename S, int REG>
 __global__ __launch_bounds__(CP_BLOCK) void k_var_applyAT(MfParams P, const double *__restrict__ y,
-                                                          const double *__restrict__ g, double *__restrict__ xo,
+                                                          const S *__restrict__ g, double *__restrict__ xo,
                                                           double *__restrict__ part) {
     __shared__ double red[CP_WAVES * 2];
     const int K = P.K, m = P.m, fs = P.fs;

@@ -34,28 +34,29 @@ enum { VSC_SGX = 11 };                       // the same, x component, from k_va
 // every image of a pixel loaded once. Addressing through buffer descriptors, range-dropped stores (cf. k_mf_fused_tv).
 struct VarRsrc { cp_rsrc y1, y2a, y2b, g, u; };
 struct VarLoads { double a, gx, gy, v0, v1, v2, v3, w0m, w1m, w2m, w3m, uxo, uyo, l0, l1, l2, l3; };
-template <bool LINEAR>
+template <typename S, bool LINEAR>
 __device__ __forceinline__ void var_load(const MfParams &P, int i, int jg, unsigned oc, unsigned fsb, const VarRsrc &R,
                                          VarLoads &q) {
     const int m = P.m;
-    const unsigned oim = oc - 8u, ojm = oc - 8u * (unsigned)m;
-    q.a = bld<double>(R.y1, oc);
-    q.gx = bld<double>(R.g, oc); q.gy = bld<double>(R.g, oc, fsb);
-    q.v0 = bld<double>(R.y2a, oc); q.v1 = bld<double>(R.y2a, oc, fsb); q.v2 = bld<double>(R.y2b, oc); q.v3 = bld<double>(R.y2b, oc, fsb);
-    q.w0m = bld<double>(R.y2a, oim); q.w2m = bld<double>(R.y2b, oim);
-    q.w1m = bld<double>(R.y2a, ojm, fsb); q.w3m = bld<double>(R.y2b, ojm, fsb);
-    q.uxo = bld<double>(R.u, oc); q.uyo = bld<double>(R.u, oc, fsb);
+    constexpr unsigned ES = (unsigned)sizeof(S);
+    const unsigned oim = oc - ES, ojm = oc - ES * (unsigned)m;
+    q.a = bld<S>(R.y1, oc);
+    q.gx = bld<S>(R.g, oc); q.gy = bld<S>(R.g, oc, fsb);
+    q.v0 = bld<S>(R.y2a, oc); q.v1 = bld<S>(R.y2a, oc, fsb); q.v2 = bld<S>(R.y2b, oc); q.v3 = bld<S>(R.y2b, oc, fsb);
+    q.w0m = bld<S>(R.y2a, oim); q.w2m = bld<S>(R.y2b, oim);
+    q.w1m = bld<S>(R.y2a, ojm, fsb); q.w3m = bld<S>(R.y2b, ojm, fsb);
+    q.uxo = bld<S>(R.u, oc); q.uyo = bld<S>(R.u, oc, fsb);
     q.l0 = q.l1 = q.l2 = q.l3 = 0.0;
     if (LINEAR) {
-        const unsigned oli = oc + 8u * (unsigned)((m - 1) - i);
+        const unsigned oli = oc + ES * (unsigned)((m - 1) - i);
         const int dj = (jg >= P.n_global - 2) ? (P.n_global - 1) - jg : 0;
-        const unsigned olj = oc + 8u * (unsigned)(dj * m);
-        q.l0 = bld<double>(R.y2a, oli); q.l2 = bld<double>(R.y2b, oli);
-        q.l1 = bld<double>(R.y2a, olj, fsb); q.l3 = bld<double>(R.y2b, olj, fsb);
+        const unsigned olj = oc + ES * (unsigned)(dj * m);
+        q.l0 = bld<S>(R.y2a, oli); q.l2 = bld<S>(R.y2b, oli);
+        q.l1 = bld<S>(R.y2a, olj, fsb); q.l3 = bld<S>(R.y2b, olj, fsb);
     }
 }
 // u_n = (u_{n-1} - tau*(A'y_n)_u) - mean at the position; abar = mean_k alpha_k there
-template <bool LINEAR>
+template <typename S, bool LINEAR>
 __device__ __forceinline__ void var_eval(const MfParams &P, int i, int jg, const VarLoads &q, double abar, double cnx, double cny,
                                          double &ux, double &uy, double &wx, double &wy) {
     const int m = P.m;
@@ -66,16 +67,16 @@ __device__ __forceinline__ void var_eval(const MfParams &P, int i, int jg, const
     const double a3 = fwd_diff_adj(q.v3, (jg >= 1) ? q.w3m : 0.0, q.l3, jg, P.n_global, LINEAR, P.inv_h2);
     const double vux = q.gx * y1c + (a0 + a1);
     const double vuy = q.gy * y1c + (a2 + a3);
-    ux = (q.uxo - P.tau * vux) - cnx;                                          // NNE/mean_zero_indicator.m:50
-    uy = (q.uyo - P.tau * vuy) - cny;                                          // :53
+    ux = rnd<S>((q.uxo - P.tau * vux) - cnx);                                  // NNE/mean_zero_indicator.m:50 (the stored value)
+    uy = rnd<S>((q.uyo - P.tau * vuy) - cny);                                  // :53
     wx = -vux;
     wy = -vuy;
 }
 
-template <bool LINEAR>
-__global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const double *__restrict__ xo, double *__restrict__ xn,
-                                                              const double *__restrict__ pin, double *__restrict__ pout,
-                                                              const double *__restrict__ g, const double *__restrict__ bbar,
+template <typename S, bool LINEAR>
+__global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
+                                                              const S *__restrict__ pin, S *__restrict__ pout,
+                                                              const S *__restrict__ g, const S *__restrict__ bbar,
                                                               const double *__restrict__ lz_in, double *__restrict__ lz_out,
                                                               const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
     constexpr int NWV = CP_WAVES;
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const d
     const double lt = P.mu1 / P.sigma;
     const double cc = P.ssd_swap ? sigma / (1.0 + sigma) : lt / (1.0 + lt);   // y1+ = cc*yt - ee*gg
     const double ee = P.ssd_swap ? sigma / (1.0 + sigma) : sigma * (lt / (1.0 + lt));
-    const unsigned mb = 8u * (unsigned)m, fsb = 8u * (unsigned)P.fs;
+    constexpr unsigned ES = (unsigned)sizeof(S);
+    const unsigned mb = ES * (unsigned)m, fsb = ES * (unsigned)P.fs;
     const cp_rsrc Rab = mk_rsrc(lz_in), Rbe = mk_rsrc(lz_in + fs), Rabo = mk_rsrc(lz_out), Rbeo = mk_rsrc(lz_out + fs);
 
     double sums[CP_NSUM], maxs[CP_NMAX];
@@ -117,7 +119,8 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const d
             const int ii = sg * 64 + lane;
             const bool valid = ii < m;
             const int i = min(ii, m - 1);
-            const unsigned off = 8u * (unsigned)((j + 1) * m + i);
+            const unsigned off = ES * (unsigned)((j + 1) * m + i);
+            const unsigned off8 = 8u * (unsigned)((j + 1) * m + i);            // the per-pixel fields abar, beta are doubles
             const bool last_i = (i == m - 1);
             const int oi = (last_i && LINEAR) ? -1 : 1;
             const int nb_lane = lane + oi;
@@ -126,29 +129,30 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const d
             const bool recompute = want && (nb_lane < 0 || nb_lane > 63) && !from_carry;
             const bool any_rc = __any(recompute);
             const unsigned offj = oj > 0 ? off + mb : off - mb;
-            const unsigned offi = oi > 0 ? off + 8u : off - 8u;
-            const unsigned off_st = valid ? off : 0xFFFFFFFFu;
+            const unsigned offi = oi > 0 ? off + ES : off - ES;
+            const unsigned offj8 = oj > 0 ? off8 + 8u * (unsigned)m : off8 - 8u * (unsigned)m, offi8 = oi > 0 ? off8 + 8u : off8 - 8u;
+            const unsigned off_st = valid ? off : 0xFFFFFFFFu, off_st8 = valid ? off8 : 0xFFFFFFFFu;
             const double vmask = valid ? 1.0 : 0.0;
             // per-pixel state of the lazy y1: abar at the own pixel, at (i, j +- 1) (and at (i +- 1, j) where that is recomputed), beta
-            const double ab = bld<double>(Rab, off), abj = bld<double>(Rab, offj), beta = bld<double>(Rbe, off);
+            const double ab = bld<double>(Rab, off8), abj = bld<double>(Rab, offj8), beta = bld<double>(Rbe, off8);
             double abi = 0.0;
-            if (any_rc) abi = bld<double>(Rab, offi);
+            if (any_rc) abi = bld<double>(Rab, offi8);
             double S_sb = 0.0, S_sc = 0.0, D1 = 0.0, D2 = 0.0, A1 = 0.0, A2 = 0.0, AG = 0.0, G1 = 0.0, GX = 0.0, GY = 0.0, GXA = 0.0,
                    GYA = 0.0;
             for (int k = 0; k < K; ++k) {
-                const double *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
-                double *o2k = pout + ((size_t)K + 4 * (size_t)k) * fs;
+                const S *y2k = pin + ((size_t)K + 4 * (size_t)k) * fs;
+                S *o2k = pout + ((size_t)K + 4 * (size_t)k) * fs;
                 const VarRsrc R = {mk_rsrc(pin + (size_t)k * fs), mk_rsrc(y2k), mk_rsrc(y2k + 2 * fs), mk_rsrc(g + 2 * (size_t)k * fs),
                                    mk_rsrc(xo + 2 * (size_t)k * fs)};
                 const cp_rsrc Run = mk_rsrc(xn + 2 * (size_t)k * fs), Ro1 = mk_rsrc(pout + (size_t)k * fs), Ro2a = mk_rsrc(o2k),
                               Ro2b = mk_rsrc(o2k + 2 * fs);
                 VarLoads q0, qj;
-                var_load<LINEAR>(P, i, jg, off, fsb, R, q0);
-                var_load<LINEAR>(P, i, jg + oj, offj, fsb, R, qj);
-                const double gg = -bld_stream<double>(mk_rsrc(bbar + (size_t)k * fs), off);   // F(y, (-b), ...)   NNE/var_tv...:172
+                var_load<S, LINEAR>(P, i, jg, off, fsb, R, q0);
+                var_load<S, LINEAR>(P, i, jg + oj, offj, fsb, R, qj);
+                const double gg = -bld_stream<S>(mk_rsrc(bbar + (size_t)k * fs), off);   // F(y, (-b), ...)   NNE/var_tv...:172
                 double ux, uy, wx, wy, uxj, uyj, wd0, wd1;
-                var_eval<LINEAR>(P, i, jg, q0, ab, cnx, cny, ux, uy, wx, wy);
-                var_eval<LINEAR>(P, i, jg + oj, qj, abj, cnx, cny, uxj, uyj, wd0, wd1);
+                var_eval<S, LINEAR>(P, i, jg, q0, ab, cnx, cny, ux, uy, wx, wy);
+                var_eval<S, LINEAR>(P, i, jg + oj, qj, abj, cnx, cny, uxj, uyj, wd0, wd1);
                 const double gx = q0.gx, gy = q0.gy;
                 const double uxb = ux + theta * (ux - q0.uxo), uyb = uy + theta * (uy - q0.uyo);
                 const double uxbj = uxj + theta * (uxj - qj.uxo), uybj = uyj + theta * (uyj - qj.uyo);
@@ -159,15 +163,15 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const d
                 if (any_rc) {
                     if (recompute) {
                         VarLoads qi;
-                        var_load<LINEAR>(P, i + oi, jg, offi, fsb, R, qi);
-                        var_eval<LINEAR>(P, i + oi, jg, qi, abi, cnx, cny, uxi, uyi, wd0, wd1);
+                        var_load<S, LINEAR>(P, i + oi, jg, offi, fsb, R, qi);
+                        var_eval<S, LINEAR>(P, i + oi, jg, qi, abi, cnx, cny, uxi, uyi, wd0, wd1);
                         uxbi = uxi + theta * (uxi - qi.uxo);
                         uybi = uyi + theta * (uyi - qi.uyo);
                     }
                 }
                 if (lane == 0) { carry[4 * k] = ux; carry[4 * k + 1] = uy; carry[4 * k + 2] = uxb; carry[4 * k + 3] = uyb; }
-                bst<double>(Run, off_st, 0u, ux);
-                bst<double>(Run, off_st, fsb, uy);
+                bst<S>(Run, off_st, 0u, ux);
+                bst<S>(Run, off_st, fsb, uy);
                 maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], valid ? wx : -1.0e300);
                 maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], valid ? -wx : -1.0e300);
                 maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], valid ? wy : -1.0e300);
@@ -177,8 +181,8 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const d
                 sums[DS_UY] += vmask * uy;
                 // ---- y1 (lazy): alpha+ = cc*(alpha + sigma*s_bar) - ee*gg; the mean of s_bar goes into beta+ after the loop ------
                 const double s_cur = gx * ux + gy * uy, s_bar = gx * uxb + gy * uyb;
-                const double an = cc * (q0.a + sigma * s_bar) - ee * gg;
-                bst<double>(Ro1, off_st, 0u, an);
+                const double an = rnd<S>(cc * (q0.a + sigma * s_bar) - ee * gg);
+                bst<S>(Ro1, off_st, 0u, an);
                 const double dk = s_cur - gg;
                 S_sb += s_bar; S_sc += s_cur; D1 += dk; D2 += dk * dk;
                 A1 += an; A2 += an * an; AG += an * gg; G1 += gg; GX += gx; GY += gy; GXA += gx * an; GYA += gy * an;
@@ -194,9 +198,9 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const d
                 sums[DS_F2] += vmask * sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);      // NNE/norm21.m:56
                 const double t0 = q0.v0 + sigma * e0, t1 = q0.v1 + sigma * e1, t2 = q0.v2 + sigma * e2, t3 = q0.v3 + sigma * e3;
                 const double nn = fmax(sqrt(t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3), P.mu2);   // :70
-                const double n0 = (P.mu2 * t0) / nn, n1 = (P.mu2 * t1) / nn, n2 = (P.mu2 * t2) / nn, n3 = (P.mu2 * t3) / nn;
-                bst<double>(Ro2a, off_st, 0u, n0); bst<double>(Ro2a, off_st, fsb, n1);
-                bst<double>(Ro2b, off_st, 0u, n2); bst<double>(Ro2b, off_st, fsb, n3);
+                const double n0 = rnd<S>((P.mu2 * t0) / nn), n1 = rnd<S>((P.mu2 * t1) / nn), n2 = rnd<S>((P.mu2 * t2) / nn), n3 = rnd<S>((P.mu2 * t3) / nn);
+                bst<S>(Ro2a, off_st, 0u, n0); bst<S>(Ro2a, off_st, fsb, n1);
+                bst<S>(Ro2b, off_st, 0u, n2); bst<S>(Ro2b, off_st, fsb, n3);
                 maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], valid ? sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3) : 0.0);   // :81
             }
             // ---- per pixel: the means that B takes, the lazy offset, the monitors of y1+ = alpha+ - beta+ -------------------------
@@ -204,8 +208,8 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const d
             const double mrb = S_sb * P.invK, mrc = S_sc * P.invK;
             const double bn = cc * (beta + sigma * mrb);
             const double abn = A1 * P.invK;
-            bst<double>(Rabo, off_st, 0u, abn);
-            bst<double>(Rbeo, off_st, 0u, bn);
+            bst<double>(Rabo, off_st8, 0u, abn);
+            bst<double>(Rbeo, off_st8, 0u, bn);
             sums[DS_F1] += vmask * ((D2 - 2.0 * mrc * D1) + Kd * mrc * mrc);             // sum_k (s_k - mrc - gg_k)^2   NNE/SSD.m:48
             const double im = 1.0 / P.mu1;
             sums[VS_Y1SQ] += vmask * (((A2 - 2.0 * bn * A1) + Kd * bn * bn) * (im * im));   // sum_k (y1+_k/mu1)^2      NNE/SSD.m:66-67
@@ -247,10 +251,10 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const d
 // (reads alpha u(2) y2(2) grad T(2) b, writes u(2) alpha = 11 elements), k_var_efused(n) (reg = 1), then k_curv_y2(n) --
 // the very kernel of the NN-curvature model: u is the first 2K fields of x and y2 follows the K fields of y1 in both --
 // (8 elements) and k_var_curv_fin(n). 19 elements instead of the 17 + 9 of the split passes, no position recomputed.
-template <bool NEUMANN>
-__global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_curv(MfParams P, const double *__restrict__ xo, double *__restrict__ xn,
-                                                                const double *__restrict__ pin, double *__restrict__ pout,
-                                                                const double *__restrict__ g, const double *__restrict__ bbar,
+template <typename S, bool NEUMANN>
+__global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_curv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
+                                                                const S *__restrict__ pin, S *__restrict__ pout,
+                                                                const S *__restrict__ g, const S *__restrict__ bbar,
                                                                 const double *__restrict__ lz_in, double *__restrict__ lz_out,
                                                                 const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
     constexpr int NWV = CP_WAVES;
@@ -267,7 +271,8 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_curv(MfParams P, const
     const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
     const double lt = P.mu1 / P.sigma;
     const double cc = lt / (1.0 + lt), ee = sigma * (lt / (1.0 + lt));   // y1+ = cc*yt - ee*gg  (NNE/SSD.m:60-61)
-    const unsigned mb = 8u * (unsigned)m, fsb = 8u * (unsigned)P.fs;
+    constexpr unsigned ES = (unsigned)sizeof(S);
+    const unsigned mb = ES * (unsigned)m, fsb = ES * (unsigned)P.fs;
     const cp_rsrc Rab = mk_rsrc(lz_in), Rbe = mk_rsrc(lz_in + fs), Rabo = mk_rsrc(lz_out), Rbeo = mk_rsrc(lz_out + fs);
 
     double sums[CP_NSUM], maxs[CP_NMAX];
@@ -291,8 +296,9 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_curv(MfParams P, const
             const int ii = sg * 64 + lane;
             const bool valid = ii < m;
             const int i = min(ii, m - 1);
-            const unsigned off = 8u * (unsigned)((j + 1) * m + i);
-            const unsigned off_st = valid ? off : 0xFFFFFFFFu;
+            const unsigned off = ES * (unsigned)((j + 1) * m + i);
+            const unsigned off8 = 8u * (unsigned)((j + 1) * m + i);            // the per-pixel fields abar, beta are doubles
+            const unsigned off_st = valid ? off : 0xFFFFFFFFu, off_st8 = valid ? off8 : 0xFFFFFFFFu;
             const bool first_i = (i == 0), last_i = (i == m - 1);
             const bool want = valid && !last_i;                    // y2_n at (i+1, j) is used
             const bool from_carry = want && lane == 63 && sg < seg_hi;
@@ -301,28 +307,28 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_curv(MfParams P, const
             const double *cin = carry + (par ^ 1) * CP_VAR_KMAX * 2;
             double *cout_ = carry + par * CP_VAR_KMAX * 2;
             const double vmask = valid ? 1.0 : 0.0;
-            const double ab = bld<double>(Rab, off), beta = bld<double>(Rbe, off);
+            const double ab = bld<double>(Rab, off8), beta = bld<double>(Rbe, off8);
             double S_sb = 0.0, S_sc = 0.0, D1 = 0.0, D2 = 0.0, A1 = 0.0, A2 = 0.0, AG = 0.0, G1 = 0.0, GX = 0.0, GY = 0.0, GXA = 0.0,
                    GYA = 0.0;
             for (int k = 0; k < K; ++k) {
                 const cp_rsrc Ry1 = mk_rsrc(pin + (size_t)k * fs), Ry2 = mk_rsrc(pin + ((size_t)K + 2 * (size_t)k) * fs),
                               Rg = mk_rsrc(g + 2 * (size_t)k * fs), Ru = mk_rsrc(xo + 2 * (size_t)k * fs),
                               Run = mk_rsrc(xn + 2 * (size_t)k * fs), Ro1 = mk_rsrc(pout + (size_t)k * fs);
-                const double al = bld<double>(Ry1, off);
-                const double gx = bld<double>(Rg, off), gy = bld<double>(Rg, off, fsb);
-                const double gg = -bld_stream<double>(mk_rsrc(bbar + (size_t)k * fs), off);   // F(y, (-b), ...)   NNE/var_curvature...:131
-                const double uxo_ = bld_stream<double>(Ru, off), uyo_ = bld_stream<double>(Ru, off, fsb);
+                const double al = bld<S>(Ry1, off);
+                const double gx = bld<S>(Rg, off), gy = bld<S>(Rg, off, fsb);
+                const double gg = -bld_stream<S>(mk_rsrc(bbar + (size_t)k * fs), off);   // F(y, (-b), ...)   NNE/var_curvature...:131
+                const double uxo_ = bld_stream<S>(Ru, off), uyo_ = bld_stream<S>(Ru, off, fsb);
                 double lap[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const unsigned so = c ? fsb : 0u;
-                    const double w0 = bld<double>(Ry2, off, so);
-                    const double wim = bld<double>(Ry2, off - 8u, so);
-                    const double wjm = bld<double>(Ry2, off - mb, so), wjp = bld<double>(Ry2, off + mb, so);
+                    const double w0 = bld<S>(Ry2, off, so);
+                    const double wim = bld<S>(Ry2, off - ES, so);
+                    const double wjm = bld<S>(Ry2, off - mb, so), wjp = bld<S>(Ry2, off + mb, so);
                     double wip = __shfl(w0, lane + 1);
                     if (from_carry) wip = cin[2 * k + c];
                     if (any_reload) {
-                        if (reload) wip = bld<double>(Ry2, off + 8u, so);
+                        if (reload) wip = bld<S>(Ry2, off + ES, so);
                     }
                     if (lane == 0) cout_[2 * k + c] = w0;
                     // NNE/discrete_laplacian.m:23-46: a missing neighbour is the centre value (neumann) or zero (dirichlet)
@@ -335,11 +341,11 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_curv(MfParams P, const
                 const double y1c = al - ab;                                        // (B*y1)_k
                 const double vux = gx * y1c + lap[0];                              // (A'y)_u = grad T * (B*y1) + Lap y2
                 const double vuy = gy * y1c + lap[1];
-                const double ux = (uxo_ - tau * vux) - cnx;                        // NNE/mean_zero_indicator.m:50,53
-                const double uy = (uyo_ - tau * vuy) - cny;
+                const double ux = rnd<S>((uxo_ - tau * vux) - cnx);                // NNE/mean_zero_indicator.m:50,53
+                const double uy = rnd<S>((uyo_ - tau * vuy) - cny);
                 const double wx = -vux, wy = -vuy;
-                bst<double>(Run, off_st, 0u, ux);
-                bst<double>(Run, off_st, fsb, uy);
+                bst<S>(Run, off_st, 0u, ux);
+                bst<S>(Run, off_st, fsb, uy);
                 maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], valid ? wx : -1.0e300);
                 maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], valid ? -wx : -1.0e300);
                 maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], valid ? wy : -1.0e300);
@@ -349,8 +355,8 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_curv(MfParams P, const
                 sums[DS_UY] += vmask * uy;
                 const double uxb = ux + theta * (ux - uxo_), uyb = uy + theta * (uy - uyo_);
                 const double s_cur = gx * ux + gy * uy, s_bar = gx * uxb + gy * uyb;
-                const double an = cc * (al + sigma * s_bar) - ee * gg;
-                bst<double>(Ro1, off_st, 0u, an);
+                const double an = rnd<S>(cc * (al + sigma * s_bar) - ee * gg);
+                bst<S>(Ro1, off_st, 0u, an);
                 const double dk = s_cur - gg;
                 S_sb += s_bar; S_sc += s_cur; D1 += dk; D2 += dk * dk;
                 A1 += an; A2 += an * an; AG += an * gg; G1 += gg; GX += gx; GY += gy; GXA += gx * an; GYA += gy * an;
@@ -359,8 +365,8 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_curv(MfParams P, const
             const double mrb = S_sb * P.invK, mrc = S_sc * P.invK;
             const double bn = cc * (beta + sigma * mrb);
             const double abn = A1 * P.invK;
-            bst<double>(Rabo, off_st, 0u, abn);
-            bst<double>(Rbeo, off_st, 0u, bn);
+            bst<double>(Rabo, off_st8, 0u, abn);
+            bst<double>(Rbeo, off_st8, 0u, bn);
             sums[DS_F1] += vmask * ((D2 - 2.0 * mrc * D1) + Kd * mrc * mrc);             // sum_k (s_k - mrc - gg_k)^2   NNE/SSD.m:48
             const double im = 1.0 / P.mu1;
             sums[VS_Y1SQ] += vmask * (((A2 - 2.0 * bn * A1) + Kd * bn * bn) * (im * im));   // NNE/SSD.m:66-67
@@ -397,20 +403,22 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_curv(MfParams P, const
 }
 
 // lazy state from a plain y1 (abar = mean_k y1_k, beta = 0) and back (y1_k = alpha_k - beta); lz = [abar field | beta field]
-__global__ __launch_bounds__(CP_BLOCK) void k_var_lazy_init(MfParams P, const double *__restrict__ p, double *__restrict__ lz) {
+template <typename S>
+__global__ __launch_bounds__(CP_BLOCK) void k_var_lazy_init(MfParams P, const S *__restrict__ p, double *__restrict__ lz) {
     for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
         const int e = q + P.m;
         double s = 0.0;
-        for (int k = 0; k < P.K; ++k) s += p[(size_t)k * P.fs + e];
+        for (int k = 0; k < P.K; ++k) s += (double)p[(size_t)k * P.fs + e];
         lz[e] = s * P.invK;
         lz[(size_t)P.fs + e] = 0.0;
     }
 }
-__global__ __launch_bounds__(CP_BLOCK) void k_var_lazy_finish(MfParams P, double *__restrict__ p, const double *__restrict__ lz) {
+template <typename S>
+__global__ __launch_bounds__(CP_BLOCK) void k_var_lazy_finish(MfParams P, S *__restrict__ p, const double *__restrict__ lz) {
     for (int q = blockIdx.x * CP_BLOCK + threadIdx.x; q < P.npix; q += gridDim.x * CP_BLOCK) {
         const int e = q + P.m;
         const double beta = lz[(size_t)P.fs + e];
-        for (int k = 0; k < P.K; ++k) p[(size_t)k * P.fs + e] -= beta;
+        for (int k = 0; k < P.K; ++k) p[(size_t)k * P.fs + e] = (S)((double)p[(size_t)k * P.fs + e] - beta);
     }
 }
 

@@ -270,7 +270,7 @@ def mf_nn_curvature_registration_no_ref_ml(img, optPara, **kw):
 
 
 # ------------------------------------------------------------------------------------------------
-def _var_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True, single_level=False):
+def _var_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True, single_level=False, fp32=False):
     """NNE/var_tv_registration_no_ref_ml.m:40-197 (and var_curvature...): multi-level loop, outer linearisations,
     power iteration, CP solve; everything but the loop control stays on the device."""
     k = len(img)
@@ -283,7 +283,7 @@ def _var_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_al
     max_outer = int(max(optPara["outerIter"]))
     u = [[None] * max_outer for _ in range(levels)]
     model = E.MODEL_VAR_TV if reg == "tv" else E.MODEL_VAR_CURV
-    flags = E.FLAG_VAR_SSD_SWAP if single_level else 0        # NNE/var_tv_registration_no_ref.m:173
+    flags = (E.FLAG_VAR_SSD_SWAP if single_level else 0) | (E.FLAG_FP32 if fp32 else 0)   # NNE/var_tv_registration_no_ref.m:173; fp32: storage mode of the engine
     sizes = [(m, n)]
     for _ in range(levels - 1):
         sizes.insert(0, ((sizes[0][0] + 1) // 2, (sizes[0][1] + 1) // 2))

@@ -45,11 +45,12 @@ for tag, model, el, mu in (("c4", E.MODEL_MF_NN_CURV, 31, 20.0), ("var", E.MODEL
     imgs = synth.dynamic_test_image(m, n, k, device=dev).transpose(1, 2).contiguous().cpu().numpy().reshape(-1)
     u0 = synth.smooth_displacement(m, n, k, amp=2.0, device=dev).cpu().numpy().reshape(-1)
     torch.cuda.empty_cache()
-    eng = E.Engine(model, m, n, k=k, bc="dirichlet" if tag in ("c4", "varc") else "neumann", omega=[0.0, float(m), 0.0, float(n)], mu=mu)
+    fl32 = E.FLAG_FP32 if os.environ.get("BENCH_FP32", "0") == "1" else 0
+    eng = E.Engine(model, m, n, k=k, bc="dirichlet" if tag in ("c4", "varc") else "neumann", omega=[0.0, float(m), 0.0, float(n)], mu=mu, flags=fl32)
     eng.set_images(imgs)
     eng.set_primal(np.concatenate([u0, np.zeros(k*m*n)]) if tag == "c4" else u0); eng.linearize()
     if tag == "c4": eng.set_nu(30.0)
-    run({"c4": "C4 NN-curvature", "var": "var-TV", "varc": "var-curvature"}[tag] + " 4096^2 x 16", eng, 1.0, 0.1, 0.1, 20, el * 8.0 * k * m * n); eng.close()
+    run({"c4": "C4 NN-curvature", "var": "var-TV", "varc": "var-curvature"}[tag] + " 4096^2 x 16" + (" fp32 storage" if fl32 else ""), eng, 1.0, 0.1, 0.1, 20, el * (4.0 if fl32 else 8.0) * k * m * n); eng.close()
 if "c1" in which:
     # C1: TV-L1 denoising of Data/rect1.png (fixture copy) with the committed salt & pepper mask, PDO/test_TV_L1_denoising.m
     from ma_amd import drivers as D

@@ -88,8 +88,7 @@ def test_fp32_denoise_and_batch():
         one.solve(1.0, 4.0, (1 - 1e-4) / 32, 20, 1e-3)
         assert np.array_equal(one.primal(), xb[s])
         one.close()
-    with pytest.raises(E.CpEngineError, match="unsupported"):
-        E.Engine(E.MODEL_VAR_TV, 16, 16, k=3, flags=E.FLAG_FP32)
+    E.Engine(E.MODEL_VAR_TV, 16, 16, k=3, flags=E.FLAG_FP32).close()                            # variance models too (below)
     E.Engine(E.MODEL_MF_NN_TV, 16, 8, k=3, n_global=16, j_offset=0, flags=E.FLAG_FP32).close()   # slabs take fp32 storage (tests/test_gpu_slab.py)
 
 
@@ -170,3 +169,57 @@ def test_fp32_mf_nn_multilevel_driver():
     print("driver fp32 vs fp64: u", ru, "L", rl)
     assert ru < 10 * TOL32 and rl < TOL32     # two levels, five re-linearisations: rounding differences compound
     np.testing.assert_allclose(SV32[-1], SV64[-1], rtol=1e-3, atol=1e-4 * SV64[-1].max())
+
+
+@pytest.mark.parametrize("reg,bc,m,n,k,mu", [("tv", "neumann", 48, 40, 3, 0.1), ("tv", "linear", 33, 50, 4, 0.1),
+                                             ("curvature", "dirichlet", 40, 36, 5, 5.0), ("curvature", "neumann", 70, 55, 3, 5.0)])
+def test_fp32_variance_models_match_oracle(reg, bc, m, n, k, mu):
+    """variance models in the fp32 storage mode (k_var_lazy_tv / k_var_lazy_curv<float>: fields as float, the per-pixel lazy
+    fields, the arithmetic and the histories in double): 60 iterations from a dual start that is not mean-free over the
+    images, against the fp64 oracle within north_star's 1e-4 (measured: ~1e-7)"""
+    from ma_amd import engine as E, synth
+    from oracle import drivers as od, prox as px
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    u0 = synth.smooth_displacement(m, n, k, amp=1.5).numpy().reshape(k, 2, n * m)
+    u0_ref = np.transpose(u0, (2, 1, 0))
+    omega, h = [0.0, float(m), 0.0, float(n)], (1.0, 1.0)
+    A, b, T_u, gs = od.var_problem([imgs[i] for i in range(k)], u0_ref, h, omega, reg, bc)
+    tau = sigma = 0.25 if reg == "tv" else 0.1
+    ncomp = 5 if reg == "tv" else 3
+    rng = np.random.default_rng(3)
+    x0 = u0.reshape(-1)
+    y0 = 0.01 * rng.standard_normal(ncomp * k * m * n) + 0.005
+    iters = 60
+    Fh = lambda y, c, nargout: od.var_F(y, -b, k, h, mu, sigma, c, nargout, reg)
+    Gh = lambda x, c, nargout: px.mean_zero_indicator(x, (m, n, k), c, nargout)
+    xr, yr, phr, dhr = cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, sigma, iters, 0.0)
+    eng = E.Engine(E.MODEL_VAR_TV if reg == "tv" else E.MODEL_VAR_CURV, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu, flags=E.FLAG_FP32)
+    eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+    eng.set_primal(x0)
+    eng.linearize()
+    eng.set_dual(y0)
+    est, npow = eng.norm_estimate()
+    eng.solve(1.0, tau, sigma, iters, 0.0)
+    x, y = eng.primal(), eng.dual()
+    ph, dh = eng.history()
+    eng.close()
+    print("fp32 var", reg, bc, "x", _rel(x, xr), "y", _rel(y, yr), "p", abs(ph[-1, 0] - phr[-1, 0]) / abs(phr[-1, 0]))
+    assert ph.shape == phr.shape
+    assert _rel(x, xr) < TOL32 and _rel(y, yr) < TOL32
+    assert abs(ph[-1, 0] - phr[-1, 0]) <= TOL32 * abs(phr[-1, 0]) and abs(dh[-1, 0] - dhr[-1, 0]) <= TOL32 * abs(dhr[-1, 0])
+    assert np.array_equal(x, x.astype(np.float32).astype(np.float64))          # what comes back is representable in fp32
+
+
+def test_fp32_variance_multilevel_driver():
+    """var_tv_registration_no_ref_ml in the fp32 storage mode (x2 prolongation, power iteration) against the fp64 mode"""
+    from ma_amd import synth
+    from ma_amd.drivers import _var_ml
+    m, n, k = 96, 80, 4
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    optPara = dict(theta=1.0, maxIter=60, tol=1e-3, outerIter=[3, 2], mu=0.1, bc="neumann")
+    u64 = _var_ml([imgs[i] for i in range(k)], optPara, "tv")
+    u32 = _var_ml([imgs[i] for i in range(k)], optPara, "tv", fp32=True)
+    a, b = u64[-1][optPara["outerIter"][1] - 1], u32[-1][optPara["outerIter"][1] - 1]
+    print("fp32 var driver", _rel(b, a))
+    assert _rel(b, a) < TOL32
