@@ -68,7 +68,7 @@ enum {
  * term as SSD(y1, b, sigma, 1, flag) (lambda and tau exchanged) while its value calls (:192) use (1, sigma); set
  * this flag to reproduce that driver, leave it clear for the *_ml drivers. */
 enum cp_flag { CP_FLAG_VAR_SSD_SWAP = 1,
-               /* fp32 mode of the pairwise and mf_nn models (not the variance models, not row slabs): state (x, y)
+               /* fp32 mode (every model; row slabs too): state (x, y)
                 * and linearisation (T(u0), grad T, b) are stored as float on the device -- half the HBM traffic
                 * per iteration; arithmetic, reductions, eigensolves, the power iteration and histories stay fp64. The host interface is unchanged (double buffers in and out). Tolerance vs the fp64 mode:
                 * 1e-4 relative on the displacement field and the energies (north_star). */
