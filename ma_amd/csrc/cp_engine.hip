@@ -95,6 +95,7 @@ struct cp_engine {
     int fused_cw = 1;    // image columns per wavefront of k_mf_fused_tv (template parameter CW; CP_TUNE_FUSED_CW)
     int fused_waves = CP_WAVES;   // wavefronts (adjacent columns) per workgroup of k_mf_fused_tv (NWV; CP_TUNE_FUSED_WAVES = 4 | 8)
     int nblk_tv = 0;              // its grid
+    int var_waves = CP_WAVES, nblk_var = 0;   // the same for k_var_lazy_tv (CP_TUNE_VAR_WAVES = 4 | 8)
     int fused_ka = 1;    // use the K <= 4 / 8 / 12 instantiations of k_mf_fused_tv (CP_TUNE_FUSED_KA=0: always 16)
     int nblk_fused = 0;  // grid of k_mf_fused_tv / k_mf_fused_curv (2 workgroups per CU resident: two LDS tiles per wave)
     int nblk_y2 = 0;     // grid of k_curv_y2
@@ -368,6 +369,13 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             h->K != CP_KMAX || (!force8 && (fused2_tasks(h->m, h->nl, 1, 8) < 256 || (h->d.flags & CP_FLAG_FP32))))   // fp32 storage: 5.5 vs 6.9 ms with 4 waves
             h->fused_waves = CP_WAVES;
         h->nblk_tv = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw, h->fused_waves) + 7) / 8 * 8, CP_FUSED_MAXGRID);
+        {
+            h->var_waves = 8;
+            bool force8v = false;
+            if (const char *ev = getenv("CP_TUNE_VAR_WAVES")) { if (atoi(ev) == 4) h->var_waves = CP_WAVES; force8v = atoi(ev) == 8; }
+            if (!(var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (!force8v && (fused2_tasks(h->m, h->nl, 1, 8) < 256 || h->fp32))) h->var_waves = CP_WAVES;
+            h->nblk_var = (int)std::min<long long>((fused2_tasks(h->m, h->nl, 1, h->var_waves) + 7) / 8 * 8, CP_FUSED_MAXGRID);
+        }
         h->curv_fused = mf && !var && h->reg == 1;
         h->var_fused = var && h->nl == h->d.n_global;
         if (const char *ev = getenv("CP_TUNE_VAR_SPLIT")) { if (atoi(ev) != 0) h->var_fused = false; }
@@ -378,6 +386,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (const char *ev = getenv("CP_TUNE_TIME_ALL")) h->time_all = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_FUSED_GRID")) h->nblk_fused = std::max(8, std::min(h->nblk_fused, atoi(ev) / 8 * 8));
         h->nblk_tv = std::min(h->nblk_tv, h->nblk_fused);
+        h->nblk_var = std::min(h->nblk_var, h->nblk_fused);
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
             HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
@@ -1095,7 +1104,8 @@ static void launch_var_fused_t(cp_engine *h, const MfParams &P, const double *xp
     }
     const bool lin = (h->d.bc == CP_BC_LINEAR);
     auto kern = lin ? k_var_lazy_tv<S, true> : k_var_lazy_tv<S, false>;
-    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, xps, (S *)xc, pcs, (S *)pn, gs, bs, lzi, lzo,
+    if (h->var_waves == 8) kern = k_var_lazy_tv<S, false, 8>;
+    hipLaunchKernelGGL(kern, dim3(h->nblk_var), dim3(64 * h->var_waves), 0, h->stream, P, xps, (S *)xc, pcs, (S *)pn, gs, bs, lzi, lzo,
                        (const CpCtrl *)h->ctrl, h->part);
 }
 static void launch_var_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn) {
@@ -1111,7 +1121,7 @@ static int var_fused_iterations(cp_engine *h, const MfParams &P, int n0, int cou
         VarEFusedArgs A = var_efused_args(P, n, 0, check, tol);
         A.reg = h->reg;
         if (h->time_all) CPCHK(timer_begin(h, T_EIG));
-        const double *rows = staged_partials(h, h->nblk_fused, &A.nblk, true);
+        const double *rows = staged_partials(h, h->reg == 0 ? h->nblk_var : h->nblk_fused, &A.nblk, true);
         hipLaunchKernelGGL(k_var_efused, dim3(1), dim3(256), 0, h->stream, A, rows, (CpCtrl *)h->ctrl, h->hist_p, h->hist_d);
         if (h->time_all) CPCHK(timer_end(h, T_EIG));
         if (h->reg != 0) {   // variance-curvature: y2_{n+1} (the kernel of the NN-curvature model), then F2 / F2* / boundary term / stop rule

@@ -73,19 +73,29 @@ __device__ __forceinline__ void var_eval(const MfParams &P, int i, int jg, const
     wy = -vuy;
 }
 
-template <typename S, bool LINEAR>
-__global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
+// NWV = waves (adjacent columns) per workgroup; 8: with the LDS hand-over of the own-pixel results between neighbouring waves
+// (hs_give / hs_take, cp_mfnn_fused.cuh) instead of the (i, j+1) evaluation from memory
+template <typename S, bool LINEAR, int NWV = CP_WAVES>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_var_lazy_tv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
                                                               const S *__restrict__ pin, S *__restrict__ pout,
                                                               const S *__restrict__ g, const S *__restrict__ bbar,
                                                               const double *__restrict__ lz_in, double *__restrict__ lz_out,
                                                               const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
-    constexpr int NWV = CP_WAVES;
     __shared__ double carry_all[NWV * CP_VAR_KMAX * 4];   // [wave][image][ux, uy, uxbar, uybar] of lane 0
     __shared__ double stage_all[NWV * CP_NSCAL];
+    constexpr bool HS = (CP_FUSED_HS != 0) && !LINEAR && NWV == 8;
+    __shared__ double xch_all[HS ? (NWV - 1) * 256 : 1];
+    __shared__ int hs_flags[2 * NWV];
     const int stopped = ctrl->stop;
     const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
     if (stopped) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 2 * NWV) hs_flags[tid] = 0;
+    __syncthreads();
+    int *fl = hs_flags;
+    double *xl = xch_all + (HS && wave > 0 ? (wave - 1) * 256 : 0);
+    const double *xr = xch_all + (HS && wave < NWV - 1 ? wave * 256 : 0);
+    int pseq = 0, cseq = 0;
     double *carry = carry_all + wave * CP_VAR_KMAX * 4;
     const int K = P.K, m = P.m;
     const size_t fs = (size_t)P.fs;
@@ -115,6 +125,7 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const S
         const int jg = P.j_off + j;
         const bool last_j = (jg == P.n_global - 1);
         const int oj = (last_j && LINEAR) ? -1 : 1;
+        const bool hs_p = HS && wave > 0, hs_c = HS && wave < NWV - 1 && j + 1 < P.nl;   // wave-uniform roles (cf. k_mf_fused_tv)
         for (int sg = seg_hi; sg >= seg_lo; --sg) {
             const int ii = sg * 64 + lane;
             const bool valid = ii < m;
@@ -148,14 +159,30 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_var_lazy_tv(MfParams P, const S
                               Ro2b = mk_rsrc(o2k + 2 * fs);
                 VarLoads q0, qj;
                 var_load<S, LINEAR>(P, i, jg, off, fsb, R, q0);
-                var_load<S, LINEAR>(P, i, jg + oj, offj, fsb, R, qj);
+                if (!hs_c) var_load<S, LINEAR>(P, i, jg + oj, offj, fsb, R, qj);
                 const double gg = -bld_stream<S>(mk_rsrc(bbar + (size_t)k * fs), off);   // F(y, (-b), ...)   NNE/var_tv...:172
                 double ux, uy, wx, wy, uxj, uyj, wd0, wd1;
                 var_eval<S, LINEAR>(P, i, jg, q0, ab, cnx, cny, ux, uy, wx, wy);
-                var_eval<S, LINEAR>(P, i, jg + oj, qj, abj, cnx, cny, uxj, uyj, wd0, wd1);
+                double uxoj = 0.0, uyoj = 0.0;
+                if (HS) {
+                    if (hs_p) hs_give(xl, fl + NWV + (wave - 1), fl + wave, ++pseq, lane, ux, uy, q0.uxo, q0.uyo);
+                    if (hs_c) {
+                        if (!hs_take(xr, fl + (wave + 1), fl + NWV + wave, ++cseq, lane, uxj, uyj, uxoj, uyoj)) {
+                            var_load<S, LINEAR>(P, i, jg + oj, offj, fsb, R, qj);         // never in practice: see hs_take
+                            var_eval<S, LINEAR>(P, i, jg + oj, qj, abj, cnx, cny, uxj, uyj, wd0, wd1);
+                            uxoj = qj.uxo; uyoj = qj.uyo;
+                        }
+                    } else {
+                        var_eval<S, LINEAR>(P, i, jg + oj, qj, abj, cnx, cny, uxj, uyj, wd0, wd1);
+                        uxoj = qj.uxo; uyoj = qj.uyo;
+                    }
+                } else {
+                    var_eval<S, LINEAR>(P, i, jg + oj, qj, abj, cnx, cny, uxj, uyj, wd0, wd1);
+                    uxoj = qj.uxo; uyoj = qj.uyo;
+                }
                 const double gx = q0.gx, gy = q0.gy;
                 const double uxb = ux + theta * (ux - q0.uxo), uyb = uy + theta * (uy - q0.uyo);
-                const double uxbj = uxj + theta * (uxj - qj.uxo), uybj = uyj + theta * (uyj - qj.uyo);
+                const double uxbj = uxj + theta * (uxj - uxoj), uybj = uyj + theta * (uyj - uyoj);
                 // (i +- 1, j): lane +- 1's own result; lane 63: the hand-over of the previous step; recomputed where neither exists
                 double uxi = __shfl(ux, nb_lane), uyi = __shfl(uy, nb_lane);
                 double uxbi = __shfl(uxb, nb_lane), uybi = __shfl(uyb, nb_lane);
