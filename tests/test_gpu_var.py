@@ -193,6 +193,40 @@ def test_var_tv_lazy_state_over_a_long_run(monkeypatch):
     assert _rel(xl2, xs2) < 1e-11 and _rel(yl2, ys2) < 1e-11
 
 
+@pytest.mark.parametrize("m,n,k,fp32", [(70, 37, 5, False), (300, 21, 16, False), (129, 8, 3, False), (64, 3, 21, False),
+                                        (70, 37, 5, True)])
+def test_var_tv_wave_hand_over_equals_the_recomputation(monkeypatch, m, n, k, fp32):
+    """k_var_lazy_tv with 8 waves per workgroup takes the neighbour column's own-pixel values from the next wave through LDS
+    (hs_give / hs_take) instead of loading them again: same iterates and histories as the 4-wave instantiation (partial sums
+    are grouped by workgroup: 1e-13), with partial segments, column groups ending inside a workgroup, fewer columns than
+    waves; CP_TUNE_VAR_WAVES=8 forces the instantiation at these sizes and in fp32 storage"""
+    from ma_amd import engine as E, synth
+    imgs = synth.dynamic_test_image(m, n, k).numpy()
+    u0 = synth.smooth_displacement(m, n, k, amp=1.0).numpy().reshape(-1)
+    omega, h = [0.0, float(m), 0.0, float(n)], (1.0, 1.0)
+    y0 = 0.05 * np.random.default_rng(5).standard_normal(5 * k * m * n) + 0.01
+
+    def run(waves):
+        monkeypatch.setenv("CP_TUNE_VAR_WAVES", waves)
+        eng = E.Engine(E.MODEL_VAR_TV, m, n, k=k, bc="neumann", h=h, omega=omega, mu=0.1, flags=E.FLAG_FP32 if fp32 else 0)
+        eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+        eng.set_primal(u0)
+        eng.linearize()
+        eng.set_dual(y0)
+        res = eng.solve(1.0, 0.25, 0.25, 80, 1e-3)
+        out = (eng.primal(), eng.dual()) + tuple(eng.history()) + (res.iterations,)
+        eng.close()
+        return out
+
+    a, b = run("8"), run("4")
+    assert a[4] == b[4]
+    tol = 1e-6 if fp32 else 1e-13
+    for u, v in zip(a[:2], b[:2]):
+        assert np.linalg.norm(u - v) <= tol * np.linalg.norm(v)
+    for u, v in zip(a[2:4], b[2:4]):
+        np.testing.assert_allclose(u, v, rtol=1e3 * tol, atol=10 * tol)
+
+
 @pytest.mark.parametrize("bc", ["dirichlet", "neumann"])
 def test_var_curvature_two_pass_path_over_a_long_run(monkeypatch, bc):
     """k_var_lazy_curv + k_curv_y2 + k_var_curv_fin (cp_var_fused.cuh) against the oracle and the split passes: 250 iterations,
