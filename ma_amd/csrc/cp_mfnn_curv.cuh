@@ -198,6 +198,17 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_curv(MfParams P, const
 // are lane +- 1's window values (cross-lane shift), lanes 0 and 63 load the two rows outside the segment. The four waves of
 // a workgroup are four vertically adjacent segments (256 rows), so three of every four of those rows are lines the
 // neighbouring wave streams at the same moment. Tasks: (row block, column strip, field group).
+// The march issues the loads of CP_Y2_CB columns as one group through buffer descriptors (3 full loads and 4 one-lane
+// loads per column; positions that do not exist are out of the descriptor's range) and stores unconditionally the same way:
+// the first version loaded one column per step behind a branch and a full wait (one round trip per column, 7.8 MB in
+// flight on the chip: 4.06 ms at 4096^2 x 16); groups of 4 and tasks of 4 fields (16384 tasks, no tail of half-empty
+// CUs): 3.55 ms = 5.2 TB/s of the 18.4 GB it moves (groups of 2: 3.71, of 8: 3.62).
+#ifndef CP_Y2_CB
+#define CP_Y2_CB 4          // columns whose loads are issued together
+#endif
+#ifndef CP_Y2_MINTASKS
+#define CP_Y2_MINTASKS 16384
+#endif
 struct CurvY2Geom { int rblocks, strips, strips8, strip_w, fgroups, fields_per_group; };
 __host__ __device__ inline CurvY2Geom curv_y2_geom(int m, int nl, int K) {
     CurvY2Geom G;
@@ -205,7 +216,7 @@ __host__ __device__ inline CurvY2Geom curv_y2_geom(int m, int nl, int K) {
     G.strip_w = nl < 32 ? nl : 32;
     G.strips = (nl + G.strip_w - 1) / G.strip_w;
     G.fgroups = 1;
-    while ((long long)G.rblocks * G.strips * G.fgroups < 2048 && G.fgroups < 2 * K) G.fgroups *= 2;
+    while ((long long)G.rblocks * G.strips * G.fgroups < CP_Y2_MINTASKS && G.fgroups < 2 * K) G.fgroups *= 2;
     G.fields_per_group = (2 * K + G.fgroups - 1) / G.fgroups;
     G.fgroups = (2 * K + G.fields_per_group - 1) / G.fields_per_group;
     G.strips8 = (G.strips + 7) / 8;
@@ -218,7 +229,7 @@ __host__ __device__ inline long long curv_y2_tasks(int m, int nl, int K) {
     return 8LL * G.rblocks * G.strips8 * G.fgroups;
 }
 
-template <typename S, bool NEUMANN>
+template <typename S, bool NEUMANN, int CB = CP_Y2_CB>
 __global__ __launch_bounds__(CP_BLOCK) void k_curv_y2(MfParams P, const S *__restrict__ xc, const S *__restrict__ xo,
                                                       const S *__restrict__ pin, S *__restrict__ pout,
                                                       const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_curv_y2(MfParams P, const S *__res
     const double sigma = P.sigma, theta = P.theta, inv_sigma = 1.0 / P.sigma;
     const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
     const double den = 1.0 + P.mu2 * inv_sigma;
-    constexpr unsigned ES = (unsigned)sizeof(S);
+    constexpr unsigned ES = (unsigned)sizeof(S), kNone = 0xFFFFFFFFu;
     const unsigned mb = ES * (unsigned)m;
     double sums[CP_NSUM], maxs[CP_NMAX];
 #pragma unroll
@@ -256,46 +267,67 @@ __global__ __launch_bounds__(CP_BLOCK) void k_curv_y2(MfParams P, const S *__res
         // never needs one (its value is not used)
         const bool edge_dn = (lane == 0) && !first_i, edge_up = (lane == 63) && valid && !last_i;
         for (int f = f0; f < f1; ++f) {
-            const S *un = xc + (size_t)f * fs, *uo = xo + (size_t)f * fs;
-            const S *y2i = pin + ((size_t)K + f) * fs;
-            S *y2o = pout + ((size_t)K + f) * fs;
+            // one descriptor per field (uniform: SALU), one 32-bit offset per position; positions that do not exist (columns
+            // past the strip, the outside rows of lanes 1..62, lanes past the end of a column for the store) carry the
+            // offset 2^32-1 and the range check drops them: no branch around a memory operation, exact wait counts
+            const cp_rsrc r_un = mk_rsrc(xc + (size_t)f * fs), r_uo = mk_rsrc(xo + (size_t)f * fs);
+            const cp_rsrc r_yi = mk_rsrc(pin + ((size_t)K + f) * fs), r_yo = mk_rsrc(pout + ((size_t)K + f) * fs);
             unsigned off = ES * (unsigned)((j0 + 1) * m + i);     // (i, j0)
-            double an_m = ldo(un, off - mb), ao_m = ldo(uo, off - mb);   // column j0 - 1 (halo column at the slab's edge)
-            double an_c = ldo_stream(un, off), ao_c = ldo_stream(uo, off);
-            for (int j = j0; j < j1; ++j, off += mb) {
-                const int jg = P.j_off + j;
-                const bool first_j = (jg == 0), last_j = (jg == P.n_global - 1);
-                // the last column of a strip is the first of the next one: a plain (cacheable) load there
-                const double an_p = (j + 1 < j1) ? ldo_stream(un, off + mb) : ldo(un, off + mb);
-                const double ao_p = (j + 1 < j1) ? ldo_stream(uo, off + mb) : ldo(uo, off + mb);
-                const double v = ldo_stream(y2i, off);
-                double an_u = __shfl(an_c, lane + 1), ao_u = __shfl(ao_c, lane + 1);   // (i+1, j)
-                double an_d = __shfl(an_c, lane - 1), ao_d = __shfl(ao_c, lane - 1);   // (i-1, j)
-                if (edge_up) { an_u = ldo(un, off, (int)ES); ao_u = ldo(uo, off, (int)ES); }
-                if (edge_dn) { an_d = ldo(un, off, -(int)ES); ao_d = ldo(uo, off, -(int)ES); }
-                // as k_mf_dual: xbar at the five points first, then the Laplacian (NNE/discrete_laplacian.m:23-46)
-                const double uc0 = an_c, ub0 = an_c + theta * (an_c - ao_c);
-                const bool have[4] = {!first_i, !last_i, !first_j, !last_j};
-                const double na[4] = {an_d, an_u, an_m, an_p}, no[4] = {ao_d, ao_u, ao_m, ao_p};
-                double nb[4], nbb[4];
+            double an_m = bld<S>(r_un, off - mb), ao_m = bld<S>(r_uo, off - mb);   // column j0 - 1 (halo column at the slab's edge)
+            double an_c = bld_stream<S>(r_un, off), ao_c = bld_stream<S>(r_uo, off);
+            for (int jb = j0; jb < j1; jb += CB, off += CB * mb) {
+                // all loads of CB columns first: column j+1 of u_n, u_{n-1} (the last one of the block with a plain load:
+                // at the end of a strip it is the first column of the next strip), y2 at j, and the four outside rows
+                S rp_n[CB], rp_o[CB], rv[CB], ru_n[CB], ru_o[CB], rd_n[CB], rd_o[CB];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    nb[d] = have[d] ? na[d] : (NEUMANN ? uc0 : 0.0);
-                    nbb[d] = have[d] ? na[d] + theta * (na[d] - no[d]) : (NEUMANN ? ub0 : 0.0);
+                for (int c = 0; c < CB; ++c) {
+                    const bool in = jb + c < j1;                  // wave-uniform
+                    const unsigned o = off + (unsigned)c * mb;
+                    const unsigned o_p = in ? o + mb : kNone, o_c = in ? o : kNone;
+                    if (c + 1 < CB) { rp_n[c] = bld_raw_stream<S>(r_un, o_p); rp_o[c] = bld_raw_stream<S>(r_uo, o_p); }
+                    else { rp_n[c] = bld_raw<S>(r_un, o_p); rp_o[c] = bld_raw<S>(r_uo, o_p); }
+                    rv[c] = bld_raw_stream<S>(r_yi, o_c);
+                    const unsigned o_u = (in && edge_up) ? o + ES : kNone, o_d = (in && edge_dn) ? o - ES : kNone;
+                    ru_n[c] = bld_raw<S>(r_un, o_u); ru_o[c] = bld_raw<S>(r_uo, o_u);
+                    rd_n[c] = bld_raw<S>(r_un, o_d); rd_o[c] = bld_raw<S>(r_uo, o_d);
                 }
-                const double lapc = (nb[0] + nb[1] - 2.0 * uc0) * ih1 + (nb[2] + nb[3] - 2.0 * uc0) * ih2;
-                const double lapb = (nbb[0] + nbb[1] - 2.0 * ub0) * ih1 + (nbb[2] + nbb[3] - 2.0 * ub0) * ih2;
-                const double t0 = v + sigma * lapb;
-                const double n0 = rnd<S>(t0 - sigma * ((t0 * inv_sigma) / den));      // NNE/SSD.m:60-61 with :43 (g = 0)
-                if (valid) {
-                    sto(y2o, off, n0);
-                    sums[DS_F2] += lapc * lapc;                                       // NNE/SSD.m:48 (g = 0)
-                    const double z0 = n0 / P.mu2;
-                    sums[DS_F2S] += z0 * z0;                                          // NNE/SSD.m:66-67
-                    const double rs = lap_rowsum(NEUMANN, first_i, last_i, first_j, last_j, ih1, ih2);
-                    if (f & 1) sums[DS_BSY] += n0 * rs; else sums[DS_BSX] += n0 * rs;
+                if (sizeof(S) == 4) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const int j = jb + c;
+                    const bool in = j < j1;
+                    const int jg = P.j_off + j;
+                    const bool first_j = (jg == 0), last_j = (jg == P.n_global - 1);
+                    const double an_p = (double)rp_n[c], ao_p = (double)rp_o[c], v = (double)rv[c];
+                    double an_u = __shfl(an_c, lane + 1), ao_u = __shfl(ao_c, lane + 1);   // (i+1, j)
+                    double an_d = __shfl(an_c, lane - 1), ao_d = __shfl(ao_c, lane - 1);   // (i-1, j)
+                    if (edge_up) { an_u = (double)ru_n[c]; ao_u = (double)ru_o[c]; }
+                    if (edge_dn) { an_d = (double)rd_n[c]; ao_d = (double)rd_o[c]; }
+                    // as k_mf_dual: xbar at the five points first, then the Laplacian (NNE/discrete_laplacian.m:23-46)
+                    const double uc0 = an_c, ub0 = an_c + theta * (an_c - ao_c);
+                    const bool have[4] = {!first_i, !last_i, !first_j, !last_j};
+                    const double na[4] = {an_d, an_u, an_m, an_p}, no[4] = {ao_d, ao_u, ao_m, ao_p};
+                    double nb[4], nbb[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        nb[d] = have[d] ? na[d] : (NEUMANN ? uc0 : 0.0);
+                        nbb[d] = have[d] ? na[d] + theta * (na[d] - no[d]) : (NEUMANN ? ub0 : 0.0);
+                    }
+                    const double lapc = (nb[0] + nb[1] - 2.0 * uc0) * ih1 + (nb[2] + nb[3] - 2.0 * uc0) * ih2;
+                    const double lapb = (nbb[0] + nbb[1] - 2.0 * ub0) * ih1 + (nbb[2] + nbb[3] - 2.0 * ub0) * ih2;
+                    const double t0 = v + sigma * lapb;
+                    const double n0 = rnd<S>(t0 - sigma * ((t0 * inv_sigma) / den));      // NNE/SSD.m:60-61 with :43 (g = 0)
+                    const bool live = valid && in;
+                    bst<S>(r_yo, live ? off + (unsigned)c * mb : kNone, 0u, n0);
+                    if (live) {
+                        sums[DS_F2] += lapc * lapc;                                       // NNE/SSD.m:48 (g = 0)
+                        const double z0 = n0 / P.mu2;
+                        sums[DS_F2S] += z0 * z0;                                          // NNE/SSD.m:66-67
+                        const double rs = lap_rowsum(NEUMANN, first_i, last_i, first_j, last_j, ih1, ih2);
+                        if (f & 1) sums[DS_BSY] += n0 * rs; else sums[DS_BSX] += n0 * rs;
+                    }
+                    an_m = an_c; ao_m = ao_c; an_c = an_p; ao_c = ao_p;
                 }
-                an_m = an_c; ao_m = ao_c; an_c = an_p; ao_c = ao_p;
             }
         }
     }
