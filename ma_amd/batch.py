@@ -9,7 +9,7 @@ ma_amd.drivers.tv_registration runs it for one pair."""
 import numpy as np
 
 from . import engine as E
-from .drivers import normalize, _vecF
+from .drivers import normalize, _vecF, _stackF
 
 
 def shard_range(nprob, world, rank):
@@ -43,7 +43,7 @@ class BatchRegistration:
         if self.P:
             self.eng = E.Engine(model, self.m, self.n, h=h, lam=lam, device=device, batch=self.P,
                                 flags=E.FLAG_FP32 if fp32 else 0)
-            self.eng.set_images(np.concatenate([_vecF(t) for t in T]), np.concatenate([_vecF(r) for r in R]))
+            self.eng.set_images(_stackF(T), _stackF(R))
 
     def run(self, maxIter, numSteps, tol=1e-3):
         """numSteps outer re-linearisations (warm start on the device), maxIter CP iterations each.

@@ -670,6 +670,20 @@ extern "C" int cp_singular_values(cp_handle h, int which, double *sv) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// sum of squares over the pixels of `nfields` fields of doubles (start vector of the power iteration)
+__global__ __launch_bounds__(CP_BLOCK) void k_sumsq_fields(int npix, int m, int fs, int nfields, const double *__restrict__ x,
+                                                           double *__restrict__ part) {
+    __shared__ double red[CP_WAVES * 2];
+    double ss[1] = {0.0}, mm[1] = {0.0};
+    const long long tot = (long long)npix * nfields;
+    for (long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot; gid += (long long)gridDim.x * CP_BLOCK) {
+        const int f = (int)(gid / npix), q = (int)(gid - (long long)f * npix);
+        const double v = x[(size_t)f * fs + m + q];
+        ss[0] += v * v;
+    }
+    block_reduce_store<1, 1>(ss, mm, red, part + (size_t)blockIdx.x * CP_PSTRIDE);
+}
+
 extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int32_t *iters) {
     if (!h || !h->mf || !est) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_norm_estimate needs an mf_nn handle");
     HIPCHK(hipSetDevice(h->d.device));
@@ -693,13 +707,11 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
         return CP_OK;
     };
     double nrm2 = 0.0;
-    {
-        // reuse applyAT's reduction for ||x||^2 would need y; do it on the host once (start vector only)
-        std::vector<double> hx((size_t)h->npix * h->nxf);
-        Fp64Transfers t(h);
-        CPCHK(download_fields(h, xa, hx.data(), h->nxf));
-        for (double v : hx) nrm2 += v * v;
-    }
+    // on the device (k_sumsq_fields, as cp_mg_power_start): downloading the start vector to sum it on the host cost 2-3 s
+    // per call at 4096^2 x 16 (6.4 GB through pageable memory)
+    hipLaunchKernelGGL(k_sumsq_fields, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, h->npix, h->m, h->fs, h->nxf, xa, h->part);
+    HIPCHK(hipGetLastError());
+    CPCHK(sumsq_partials(nrm2));
     double scale = 1.0 / std::sqrt(nrm2);                       // NNE/matrix_norm.m:23
     const double tol = 1e-6;
     const int maxIter = 100;
@@ -1738,19 +1750,6 @@ __global__ __launch_bounds__(CP_BLOCK) void k_halo_state(int m, int fs, int K, i
         }
         if (pack) *q = *p; else *p = *q;
     }
-}
-
-__global__ __launch_bounds__(CP_BLOCK) void k_sumsq_fields(int npix, int m, int fs, int nfields, const double *__restrict__ x,
-                                                           double *__restrict__ part) {
-    __shared__ double red[CP_WAVES * 2];
-    double ss[1] = {0.0}, mm[1] = {0.0};
-    const long long tot = (long long)npix * nfields;
-    for (long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot; gid += (long long)gridDim.x * CP_BLOCK) {
-        const int f = (int)(gid / npix), q = (int)(gid - (long long)f * npix);
-        const double v = x[(size_t)f * fs + m + q];
-        ss[0] += v * v;
-    }
-    block_reduce_store<1, 1>(ss, mm, red, part + (size_t)blockIdx.x * CP_PSTRIDE);
 }
 
 // selections CP_SEL_VEC_*: the same fields as CP_SEL_X_U / CP_SEL_P_DY / CP_SEL_P_Y2, but the buffer holds doubles in

@@ -7,6 +7,7 @@ sparse matrices cannot be fused, see INTEGRATION.md.
 """
 from dataclasses import dataclass
 import math
+import time
 
 import numpy as np
 
@@ -21,6 +22,21 @@ def normalize(x):
 
 def _vecF(a):
     return np.asarray(a, dtype=np.float64).reshape(-1, order="F")
+
+
+def _stackF(imgs):
+    """the images of a cell array as one column-major vector [img_1(:); img_2(:); ...] (what cp_set_images takes). A
+    column-major flatten of a row-major numpy array is a transposed copy; numpy's takes 0.35-1 s per 4096^2 image (16 s for
+    BASELINE config 4 on the GPU box's host), torch's blocked multi-threaded copy a third of that"""
+    import torch
+    imgs = [np.ascontiguousarray(im, dtype=np.float64) for im in imgs]
+    out = np.empty(sum(im.size for im in imgs))
+    o = 0
+    for im in imgs:
+        m, n = im.shape
+        torch.from_numpy(out[o:o + m * n]).view(n, m).copy_(torch.from_numpy(im).t())
+        o += m * n
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -161,7 +177,7 @@ def num_levels(m, n):
 
 
 def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_all=True, single_level=False,
-              fp32=False, slabs=None, slab_min_pixels=1 << 20):
+              fp32=False, slabs=None, slab_min_pixels=1 << 20, timings=None):
     """fp32=True: CP_FLAG_FP32 storage mode of the engine (fields as float, arithmetic in double); not part of the
     reference's optPara, results agree with the fp64 mode to about 1e-4 relative.
 
@@ -171,7 +187,9 @@ def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_
     -- every rank solves the whole level on its own GPU, bit for bit the same -- so the hand-over to the first slab level
     needs no communication either (the slab boundaries double from level to level). Every rank returns the full result."""
     k = len(img)
+    t_s = [time.perf_counter()]
     img = [normalize(im) for im in img]
+    t_s.append(time.perf_counter())
     m, n = img[0].shape
     omega = [0.0, float(m), 0.0, float(n)]
     levels = 1 if single_level else num_levels(m, n)
@@ -209,10 +227,14 @@ def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_
             else:
                 engines.append(E.Engine(model, ml, nl, k=k, bc=optPara["bc"], h=h_grid, omega=omega, mu=optPara["mu"],
                                         device=device, flags=flags))
-        engines[-1].set_images(np.concatenate([_vecF(im) for im in img]))
+        t_s.append(time.perf_counter())
+        engines[-1].set_images(_stackF(img))
+        t_s.append(time.perf_counter())
         for lev in range(levels - 1, 0, -1):
             engines[lev].downsample_to(engines[lev - 1])
         nu = None
+        if timings is not None:
+            timings.update(normalize=t_s[1] - t_s[0], create=t_s[2] - t_s[1], set_images=t_s[3] - t_s[2], prolong=0.0, download=0.0)
         for lev in range(levels):
             eng = engines[lev]
             ml, nl = sizes[lev]
@@ -220,10 +242,14 @@ def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_
             outerIter = int(optPara["outerIter"][sel])
             nu_factor = optPara["nu_factor"][sel]
             if lev > 0:
+                t_p = time.perf_counter()
                 eng.prolong_from(engines[lev - 1], 1.0)                                # (:111-119), p = 0 (:122)
                 engines[lev - 1].close()
+                if timings is not None:
+                    timings["prolong"] += time.perf_counter() - t_p
             SV_history[lev] = np.zeros((k, outerIter))                                 # (:153): this level's outerIter
             for o in range(outerIter):
+                t_0 = time.perf_counter()
                 eng.linearize()                                                        # (:164-169)
                 if o == 0 and lev == 0:
                     nu = nu_factor * float(np.sum(eng.singular_values(0)))             # (:173-175)
@@ -233,22 +259,30 @@ def _mf_nn_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_
                     nu = nu_factor * nu                                                # (:179)
                 eng.set_nu(nu)
                 x0n = normest_x0(3 * k * ml * nl) if (normest_x0 is not None and lev not in parts) else None
+                t_1 = time.perf_counter()
                 norm_A_est, n_power = eng.norm_estimate(x0n)                           # (:191-192)
+                t_2 = time.perf_counter()
                 tau = math.sqrt(0.99 / norm_A_est ** 2)
                 sigma = math.sqrt(0.99 / norm_A_est ** 2)
                 res = eng.solve(optPara["theta"], tau, sigma, optPara["maxIter"], optPara["tol"])
+                t_3 = time.perf_counter()
                 last = (lev == levels - 1) and (o == outerIter - 1)
                 if download_all or last:
+                    t_d = time.perf_counter()
                     x = eng.primal_full() if lev in parts else eng.primal()
                     kmn = k * ml * nl
                     u[lev][o] = x[: 2 * kmn].reshape((ml * nl, 2, k), order="F")
                     L[lev][o] = x[2 * kmn:].reshape((ml, nl, k), order="F")
+                    if timings is not None:
+                        timings["download"] += time.perf_counter() - t_d
                 SV_history[lev][:, o] = eng.singular_values(1)                         # (:214-215)
                 if keep is not None:
                     ph, dh = eng.history()
                     keep[(lev, o)] = dict(nu=nu, tau=tau, sigma=sigma, norm_est=norm_A_est, n_power=n_power,
                                           primal_history=ph, dual_history=dh, iterations=res.iterations,
-                                          stop_reason=res.stop_reason)
+                                          stop_reason=res.stop_reason,
+                                          seconds=dict(linearize=t_1 - t_0, norm_estimate=t_2 - t_1, solve=t_3 - t_2,
+                                                       rest=time.perf_counter() - t_3))
         return u, L, SV_history
     finally:
         for e in engines:
@@ -295,7 +329,7 @@ def _var_ml(img, optPara, reg, device=0, normest_x0=None, keep=None, download_al
             # [0, m*h1, 0, n*h2] is that call's default (IRE/evaluate_displacement.m:34-36)
             engines.append(E.Engine(model, ml, nl, k=k, bc=optPara["bc"], h=h_grid, omega=None, mu=optPara["mu"],
                                     device=device, flags=flags))
-        engines[-1].set_images(np.concatenate([_vecF(im) for im in img]))
+        engines[-1].set_images(_stackF(img))
         for lev in range(levels - 1, 0, -1):
             engines[lev].downsample_to(engines[lev - 1])                                # (:71-74)
         for lev in range(levels):

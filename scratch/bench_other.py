@@ -91,12 +91,20 @@ if "c4drv" in which:
     optPara = dict(theta=1.0, maxIter=2000, tol=5e-3, outerIter=[16, 2], mu=2e1, nu_factor=[0.95, 0.95], bc="dirichlet", doPlots=False)
     keep = {}
     t0 = time.perf_counter()
-    D._mf_nn_ml([imgs[i] for i in range(k)], optPara, "curvature", keep=keep, download_all=False)
+    tm = {}
+    D._mf_nn_ml([imgs[i] for i in range(k)], optPara, "curvature", keep=keep, download_all=False, timings=tm)
     dt = time.perf_counter() - t0
+    print(json.dumps({"host_side_seconds": {a: round(b, 3) for a, b in tm.items()},
+                      "n_power_per_level_and_outer": {f"{lev}.{o}": v["n_power"] for (lev, o), v in keep.items() if lev >= 5}}), flush=True)
     its = sum(v["iterations"] for v in keep.values())
     per_level = {}
     for (lev, o), v in keep.items():
         per_level[lev] = per_level.get(lev, 0) + v["iterations"]
+    secs = {}
+    for (lev, o), v in keep.items():
+        for kk, vv in v["seconds"].items():
+            secs.setdefault(kk, {}); secs[kk][lev] = round(secs[kk].get(lev, 0.0) + vv, 3)
+    print(json.dumps({"seconds_per_phase_and_level": secs}), flush=True)
     print(json.dumps({"workload": f"C4 mf_nn_curvature_registration_no_ref_ml K=16 {m}^2, {D.num_levels(m, n)} levels, fp64, one GPU",
                       "seconds": dt, "cp_iterations": its, "iterations_per_level": per_level,
                       "power_iterations": sum(v["n_power"] for v in keep.values()), "outer_iterations": len(keep)}), flush=True)
