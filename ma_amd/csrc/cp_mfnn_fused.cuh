@@ -521,7 +521,7 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_efused(EFusedArgs A, cons
     if (t < 256) helmert_cols(Tm[1], G2h, A.K, t >> 4, t & 15);
     __syncthreads();
     EPROF(2);
-    eig16_warm<2>(GG, VV, V0, Tm, vwarm, A.warm);   // both Gram matrices side by side, warm-started
+    eig16_warm<2>(GG, VV, V0, Tm, vwarm, A.warm, A.K);   // both Gram matrices side by side, warm-started
     EPROF(5);
     if (t < 64) l1ball_scale16(G, A.K, nu * A.sigma, zv, zs, dvec, res, ctrl->sv);   // NNE/nuclear_norm_constraint.m:72
     else if (t < 80) {   // singular values of B*L_n (K-1 after the deflation), one lane each
