@@ -92,6 +92,7 @@ struct cp_engine {
                              // events costs a few microseconds of stream time; by default only the dominant kernel is timed)
     bool pw_split = false;   // tuning aid (CP_TUNE_PW_SPLIT=1): pairwise models on the split passes instead of k_pw_fused
     bool var_fused = false;   // variance-TV: one k_var_lazy_tv + k_var_efused per iteration (CP_TUNE_VAR_SPLIT=1: split passes)
+    bool fused_ks = false;   // k_mf_fused_tv<..., KS>: one column per workgroup, the images dealt to its waves (coarsest levels; CP_TUNE_FUSED_KS_TASKS)
     int fused_cw = 1;    // image columns per wavefront of k_mf_fused_tv (template parameter CW; CP_TUNE_FUSED_CW)
     int fused_waves = CP_WAVES;   // wavefronts (adjacent columns) per workgroup of k_mf_fused_tv (NWV; CP_TUNE_FUSED_WAVES = 4 | 8)
     int nblk_tv = 0;              // its grid
@@ -386,6 +387,15 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (const char *ev = getenv("CP_TUNE_TIME_ALL")) h->time_all = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_FUSED_GRID")) h->nblk_fused = std::max(8, std::min(h->nblk_fused, atoi(ev) / 8 * 8));
         h->nblk_tv = std::min(h->nblk_tv, h->nblk_fused);
+        {
+            // measured (K = 10): 32^2 31.5 -> 22.9 us per launch, 128^2 (256 tasks, with the stage-1 reduction) 41.0 -> 27.6, 256^2 (1024 tasks) 48 -> 62
+            long long ks_tasks = 256;
+            if (const char *ev = getenv("CP_TUNE_FUSED_KS_TASKS")) ks_tasks = atoll(ev);
+            const long long t = (long long)fused2_geom(h->m, 64).parts * h->nl;
+            h->fused_ks = mf && !var && h->reg == 0 && h->d.bc != CP_BC_LINEAR && !(h->d.flags & CP_FLAG_MFNN_NORM21) &&
+                          h->fused_cw == 1 && h->fused_waves == CP_WAVES && h->K >= 2 && t <= ks_tasks;
+            if (h->fused_ks) h->nblk_tv = (int)t;
+        }
         h->nblk_var = std::min(h->nblk_var, h->nblk_fused);
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
@@ -395,7 +405,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
                     HIPCHK(hipMalloc(&h->vlazy[a], sizeof(double) * 2 * (size_t)h->fs));
                     HIPCHK(hipMemsetAsync(h->vlazy[a], 0, sizeof(double) * 2 * (size_t)h->fs, h->stream));
                 }
-            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(std::max(h->nblk, h->nblk_fused), h->nblk_y2) * CP_PSTRIDE));
+            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(std::max(std::max(h->nblk, h->nblk_fused), h->nblk_tv), h->nblk_y2) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->part2, sizeof(double) * (size_t)(CP_FUSED_MAXGRID / CP_S1_GROUP) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->svout, sizeof(double) * (16 + 256 + 256)));
             HIPCHK(hipMalloc(&h->red, sizeof(double) * CP_PSTRIDE));
@@ -919,6 +929,13 @@ static void launch_fused_t(cp_engine *h, const MfParams &P, const double *xp, do
     if (h->fused_cw == 2) kern = (h->K == CP_KMAX) ? k_mf_fused_tv<S, false, true, CP_KMAX, false, 2> : k_mf_fused_tv<S, false, false, CP_KMAX, false, 2>;
     if (h->fused_cw == 4) kern = (h->K == CP_KMAX) ? k_mf_fused_tv<S, false, true, CP_KMAX, false, 4> : k_mf_fused_tv<S, false, false, CP_KMAX, false, 4>;
     if (h->fused_waves == 8) kern = k_mf_fused_tv<S, false, true, CP_KMAX, false, 1, 8>;
+    if (h->fused_ks) {    // coarsest levels (cp_create): one column per workgroup, images dealt to its four waves
+        if (h->K == CP_KMAX) kern = k_mf_fused_tv<S, false, true, CP_KMAX, false, 1, CP_WAVES, true>;
+        else if (h->K <= 4 && h->fused_ka) kern = k_mf_fused_tv<S, false, false, 4, false, 1, CP_WAVES, true>;
+        else if (h->K <= 8 && h->fused_ka) kern = k_mf_fused_tv<S, false, false, 8, false, 1, CP_WAVES, true>;
+        else if (h->K <= 12 && h->fused_ka) kern = k_mf_fused_tv<S, false, false, 12, false, 1, CP_WAVES, true>;
+        else kern = k_mf_fused_tv<S, false, false, CP_KMAX, false, 1, CP_WAVES, true>;
+    }
     hipLaunchKernelGGL(kern, dim3(h->nblk_tv), dim3(64 * h->fused_waves), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
                        (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
 }

@@ -236,7 +236,10 @@ __device__ __forceinline__ bool hs_take(const double *slot, int *pub, int *ack, 
 // NWV = wavefronts (= adjacent image columns) per workgroup: 4 (two workgroups per CU) or 8 (one workgroup per CU, the same
 // two waves per SIMD): only the last wave's (i, j+1) lines and the first wave's (i, j-1) lines belong to another workgroup,
 // so 8 columns halve the cross-workgroup re-reads.
-template <typename S, bool LINEAR, bool FULLK, int KA = CP_KMAX, bool N21 = false, int CW = 1, int NWV = CP_WAVES>
+// KS (the coarsest pyramid levels: a handful of workgroups, one wave per SIMD, so the per-image phase is the issue rate of
+// ONE wave -- 1.5 us per image): the four waves of a workgroup share one column; each runs phase 1 (same values, same
+// stores; only wave 0's Gram tiles count) and then every fourth image of phase 2.
+template <typename S, bool LINEAR, bool FULLK, int KA = CP_KMAX, bool N21 = false, int CW = 1, int NWV = CP_WAVES, bool KS = false>
 __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
                                                               const S *__restrict__ pin, S *__restrict__ pout,
                                                               const S *__restrict__ g, const S *__restrict__ b,
@@ -291,10 +294,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
     double4_t acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 
     const Fused2Geom GM = fused2_geom(m, R);
-    const int ntasks = GM.parts * ((P.nl + NWV * CW - 1) / (NWV * CW));
+    static_assert(!KS || (CW == 1 && NWV == CP_WAVES && !LINEAR), "KS: one column per workgroup of 4 waves");
+    const int ntasks = KS ? GM.parts * P.nl : GM.parts * ((P.nl + NWV * CW - 1) / (NWV * CW));
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
         const int cg = task / GM.parts, pt = task - cg * GM.parts;
-        const int jw = (cg * NWV + wave) * CW;                     // first column of the wave's tile
+        const int jw = KS ? cg : (cg * NWV + wave) * CW;           // first column of the wave's tile
         if (jw >= P.nl) continue;                                  // wave-uniform
         const bool colv = jw + lc < P.nl;
         const int j = min(jw + lc, P.nl - 1);                      // lanes past the last column redo it, nothing is stored
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
             double *cslot = carry + lc * 4;
             const double vmask = valid ? 1.0 : 0.0;
             const unsigned off_st = valid ? off : 0xFFFFFFFFu;
-            for (int k = 0; k < K; ++k) {
+            for (int k = KS ? wave : 0; k < K; k += KS ? NWV : 1) {
                 // descriptors of this image's field groups (uniform: SALU); every position is one 32-bit VGPR offset
                 S *o2k = pout + ((size_t)K + 4 * (size_t)k) * fs;
                 const ImgRsrc R = img_rsrc<S>(pin, g, xo, K, k, fs);
@@ -446,6 +450,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
             wave_lds_sync();   // hand-over and tiles of this step are complete before the next step touches them
         }
     }
+    if (KS && wave != 0) { acc1 = double4_t{0.0, 0.0, 0.0, 0.0}; acc2 = double4_t{0.0, 0.0, 0.0, 0.0}; }   // phase 1 ran four times
     double *out = part + (size_t)blockIdx.x * CP_PSTRIDE;
     {
         constexpr int WS = 2 * 16 * CP_TS;
