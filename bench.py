@@ -41,7 +41,8 @@ def dominant_kernel(reg, k, bc, fp32, m=4096, nl=4096):
             ka = 16
         waves = os.environ.get("CP_TUNE_FUSED_WAVES", "8")                             # columns per workgroup (tuning knob)
         big = ((m + 63) // 64 if m < 512 else 8) * ((nl + 7) // 8) >= 256                # cp_create: every CU gets a workgroup
-        waves = "8" if (waves != "4" and k == 16 and bc != "linear" and cw == "1" and big and not fp32) else "4"
+        steps = -(-((m + 63) // 64) // min((m + 63) // 64, 8))                             # segments per task
+        waves = "8" if (waves != "4" and k > 4 and bc != "linear" and cw == "1" and big and steps >= 8 and not fp32) else "4"
         parts = min((m + 63) // 64, 8)
         ks = waves == "4" and bc != "linear" and cw == "1" and parts * nl <= int(os.environ.get("CP_TUNE_FUSED_KS_TASKS", "256"))
         return f"k_mf_fused_tv<{S}, {lin}, {'true' if k == 16 else 'false'}, {ka}, false, {cw}, {waves}, {'true' if ks else 'false'}>"

@@ -367,14 +367,17 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         bool force8 = false;   // CP_TUNE_FUSED_WAVES=8: also for small problems and fp32 storage (tests of the hand-over at small sizes)
         if (const char *ev = getenv("CP_TUNE_FUSED_WAVES")) { if (atoi(ev) == 4) h->fused_waves = CP_WAVES; force8 = atoi(ev) == 8; }
         if (!(mf && !var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (h->d.flags & CP_FLAG_MFNN_NORM21) || h->fused_cw != 1 ||
-            h->K != CP_KMAX || (!force8 && (fused2_tasks(h->m, h->nl, 1, 8) < 256 || (h->d.flags & CP_FLAG_FP32))))   // fp32 storage: 5.5 vs 6.9 ms with 4 waves
+            h->K <= 4 || (!force8 && (fused2_tasks(h->m, h->nl, 1, 8) < 256 || fused2_geom(h->m, 64).steps < 8 || (h->d.flags & CP_FLAG_FP32))))
+            // fp32 storage: 5.5 vs 6.9 ms with 4 waves. Fewer than 8 steps per task (m < 3585): the staircase start of the
+            // hand-over is not amortised -- 2048^2 x 16: 2.58 vs 2.55 ms, 1024^2: 0.68 vs 0.66; 4096 x 512 (a slab): 1.37 vs 1.41
+            // in favour of 8 waves. K = 5..15 (KA = 8, 12, 16 instantiations): 4096^2 x 12 7.39 vs 7.47 ms, x 8 4.83 vs 4.93
             h->fused_waves = CP_WAVES;
         h->nblk_tv = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw, h->fused_waves) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         {
             h->var_waves = 8;
             bool force8v = false;
             if (const char *ev = getenv("CP_TUNE_VAR_WAVES")) { if (atoi(ev) == 4) h->var_waves = CP_WAVES; force8v = atoi(ev) == 8; }
-            if (!(var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (!force8v && (fused2_tasks(h->m, h->nl, 1, 8) < 256 || h->fp32))) h->var_waves = CP_WAVES;
+            if (!(var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (!force8v && (fused2_tasks(h->m, h->nl, 1, 8) < 256 || fused2_geom(h->m, 64).steps < 8 || h->fp32))) h->var_waves = CP_WAVES;
             h->nblk_var = (int)std::min<long long>((fused2_tasks(h->m, h->nl, 1, h->var_waves) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         }
         h->curv_fused = mf && !var && h->reg == 1;
@@ -928,7 +931,12 @@ static void launch_fused_t(cp_engine *h, const MfParams &P, const double *xp, do
     else if (h->K <= 12 && h->fused_ka) kern = lin ? k_mf_fused_tv<S, true, false, 12> : k_mf_fused_tv<S, false, false, 12>;
     if (h->fused_cw == 2) kern = (h->K == CP_KMAX) ? k_mf_fused_tv<S, false, true, CP_KMAX, false, 2> : k_mf_fused_tv<S, false, false, CP_KMAX, false, 2>;
     if (h->fused_cw == 4) kern = (h->K == CP_KMAX) ? k_mf_fused_tv<S, false, true, CP_KMAX, false, 4> : k_mf_fused_tv<S, false, false, CP_KMAX, false, 4>;
-    if (h->fused_waves == 8) kern = k_mf_fused_tv<S, false, true, CP_KMAX, false, 1, 8>;
+    if (h->fused_waves == 8) {
+        if (h->K == CP_KMAX) kern = k_mf_fused_tv<S, false, true, CP_KMAX, false, 1, 8>;
+        else if (h->K <= 8 && h->fused_ka) kern = k_mf_fused_tv<S, false, false, 8, false, 1, 8>;
+        else if (h->K <= 12 && h->fused_ka) kern = k_mf_fused_tv<S, false, false, 12, false, 1, 8>;
+        else kern = k_mf_fused_tv<S, false, false, CP_KMAX, false, 1, 8>;
+    }
     if (h->fused_ks) {    // coarsest levels (cp_create): one column per workgroup, images dealt to its four waves
         if (h->K == CP_KMAX) kern = k_mf_fused_tv<S, false, true, CP_KMAX, false, 1, CP_WAVES, true>;
         else if (h->K <= 4 && h->fused_ka) kern = k_mf_fused_tv<S, false, false, 4, false, 1, CP_WAVES, true>;

@@ -242,15 +242,15 @@ def test_long_run_against_c_restatement():
     assert _rel(x, xr) < TOL and _rel(y, yr) < TOL
 
 
-@pytest.mark.parametrize("m,n,fp32", [(70, 37, False), (33, 8, False), (130, 21, False), (64, 16, True)])
-def test_fused_tv_wave_hand_over_equals_the_recomputation(monkeypatch, m, n, fp32):
+@pytest.mark.parametrize("m,n,fp32,k", [(70, 37, False, 16), (33, 8, False, 16), (130, 21, False, 16), (64, 16, True, 16),
+                                          (70, 37, False, 10), (130, 21, False, 7), (64, 19, False, 13), (70, 21, True, 5)])
+def test_fused_tv_wave_hand_over_equals_the_recomputation(monkeypatch, m, n, fp32, k):
     """k_mf_fused_tv with 8 waves per workgroup hands the own-pixel result of column j+1 to the wave of column j through LDS
     (cp_mfnn_fused.cuh: hs_give / hs_take) instead of recomputing it from y_n: the same iterates and histories as the 4-wave
     instantiation, which recomputes (the handed-over numbers are bitwise the recomputed ones; the partial sums are grouped by
     workgroup, so means and Gram matrices differ in the last bit: 1e-13), at sizes with partial segments, column groups that end inside a workgroup
-    and a single column group; 60 iterations with the stop rule armed"""
+    and a single column group, for K = 16 and the K < 16 instantiations (KA = 8, 12, 16); 60 iterations with the stop rule armed"""
     from ma_amd import engine as E, synth
-    k = 16
     imgs = synth.dynamic_test_image(m, n, k).numpy()
     u0 = synth.smooth_displacement(m, n, k, amp=1.0).numpy().reshape(-1)
     omega = [0.0, float(m), 0.0, float(n)]
