@@ -168,22 +168,35 @@ __device__ __forceinline__ void fused_phase1(const MfParams &P, int K, bool vali
 // four adjacent columns and run free (the tiles are wave-private: the Gram steps need only the ordering of the wave's own
 // LDS instructions, wave_lds_sync, not a workgroup barrier; they meet once, for the partial row), so the (i, j+1) loads of
 // waves 0..2 are the lines the next wave streams at the same moment. Tasks (part, column group) are dealt so that a part
-// stays on one XCD (8 parts per column when there are at least 8 segments; gridDim.x % 8 == 0) and the next column
+// stays on one XCD (8 parts per column in the 4-wave kernels when there are at least 8 segments, see fused2_cap;
+// gridDim.x % 8 == 0) and the next column
 // group's task -- whose own loads are wave 3's (i, j+1) loads -- is the next workgroup of that XCD.
 #ifndef CP_FUSED_PARTS
 #define CP_FUSED_PARTS 8
 #endif
 struct Fused2Geom { int nseg, parts, steps; };
-__host__ __device__ inline Fused2Geom fused2_geom(int m, int R = 64) {
+__host__ __device__ inline Fused2Geom fused2_geom(int m, int R = 64, int cap = CP_FUSED_PARTS) {
     Fused2Geom G;
     G.nseg = (m + R - 1) / R;
-    G.parts = G.nseg < CP_FUSED_PARTS ? G.nseg : CP_FUSED_PARTS;
+    G.parts = G.nseg < cap ? G.nseg : cap;
     G.steps = (G.nseg + G.parts - 1) / G.parts;
     G.parts = (G.nseg + G.steps - 1) / G.steps;   // drop parts that would be empty
     return G;
 }
+// Parts per column. The 8-wave hand-over kernels (k_mf_fused_tv, k_var_lazy_tv) pay a staircase start per task (wave w
+// waits for wave w+1's first image) and a recomputed (i+1, j) row at every part boundary, so they want long tasks: 2 parts
+// per column as long as that still leaves >= 1024 tasks (4096^2 x 16: 8 parts 9.35 ms, 4: 9.19, 3: 9.30, 2: 8.83-9.12,
+// 1: 9.03; var-TV 7.66 / 7.53 / - / 7.01 / 7.15), more parts for fewer column groups (a 4096 x 512 slab keeps 8).
+// The 4-wave kernels keep 8 (k_mf_fused_curv: no difference; k_var_lazy_curv: 7.81 ms with 8, 8.31 with 2, 8.87 with 1).
+__host__ __device__ inline int fused2_cap(int colgroups, int waves) {
+    if (waves != 8) return CP_FUSED_PARTS;
+    int p = 2;
+    while (p < CP_FUSED_PARTS && (long long)p * colgroups < 1024) p *= 2;
+    return p;
+}
 __host__ __device__ inline long long fused2_tasks(int m, int nl, int cw = 1, int waves = CP_WAVES) {
-    return (long long)fused2_geom(m, 64 / cw).parts * ((nl + waves * cw - 1) / (waves * cw));
+    const int colgroups = (nl + waves * cw - 1) / (waves * cw);
+    return (long long)fused2_geom(m, 64 / cw, fused2_cap(colgroups, waves)).parts * colgroups;
 }
 
 // ---- hand-over of own-pixel results between the waves of a workgroup (no workgroup barrier) --------------------------------
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
     maxs[DM_Y1 - CP_NSUM] = 0.0; maxs[DM_S1 - CP_NSUM] = 0.0; maxs[PM_VL - CP_NSUM] = 0.0;
     double4_t acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 
-    const Fused2Geom GM = fused2_geom(m, R);
+    const Fused2Geom GM = fused2_geom(m, R, fused2_cap((P.nl + NWV * CW - 1) / (NWV * CW), NWV));
     static_assert(!KS || (CW == 1 && NWV == CP_WAVES && !LINEAR), "KS: one column per workgroup of 4 waves");
     const int ntasks = KS ? GM.parts * P.nl : GM.parts * ((P.nl + NWV * CW - 1) / (NWV * CW));
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
