@@ -185,13 +185,17 @@ __host__ __device__ inline Fused2Geom fused2_geom(int m, int R = 64, int cap = C
 }
 // Parts per column. The 8-wave hand-over kernels (k_mf_fused_tv, k_var_lazy_tv) pay a staircase start per task (wave w
 // waits for wave w+1's first image) and a recomputed (i+1, j) row at every part boundary, so they want long tasks: 2 parts
-// per column as long as that still leaves >= 1024 tasks (4096^2 x 16: 8 parts 9.35 ms, 4: 9.19, 3: 9.30, 2: 8.83-9.12,
-// 1: 9.03; var-TV 7.66 / 7.53 / - / 7.01 / 7.15), more parts for fewer column groups (a 4096 x 512 slab keeps 8).
+// per column as long as that still leaves a task for every CU (4096^2 x 16: 8 parts 9.35 ms, 4: 9.19, 3: 9.30, 2: 8.83-9.12,
+// 1: 9.03; var-TV 7.66 / 7.53 / - / 7.01 / 7.15), more parts for fewer column groups: slabs of 4096 rows x 512 / 1024 / 2048
+// columns 1.38 / 2.57 / 4.67 ms with >= 1024 tasks, 1.31 / 2.49 / 4.58 with >= 256 (4, 2, 2 parts).
 // The 4-wave kernels keep 8 (k_mf_fused_curv: no difference; k_var_lazy_curv: 7.81 ms with 8, 8.31 with 2, 8.87 with 1).
 __host__ __device__ inline int fused2_cap(int colgroups, int waves) {
     if (waves != 8) return CP_FUSED_PARTS;
     int p = 2;
-    while (p < CP_FUSED_PARTS && (long long)p * colgroups < 1024) p *= 2;
+#ifndef CP_FUSED_MINTASKS8
+#define CP_FUSED_MINTASKS8 256     // one workgroup per CU
+#endif
+    while (p < CP_FUSED_PARTS && (long long)p * colgroups < CP_FUSED_MINTASKS8) p *= 2;
     return p;
 }
 __host__ __device__ inline long long fused2_tasks(int m, int nl, int cw = 1, int waves = CP_WAVES) {
