@@ -71,3 +71,51 @@ def run_case(t, rng):
     ok = ex < 1e-10 and ey < 1e-10 and eh < 1e-9
     return (dict(case=t, fam=fam, reg=reg, bc=bc, m=m, n=n, k=k, h=h, waves=waves, x=ex, y=ey, hist=eh, hist_col=int(np.argmax(dev.max(axis=0))), ok=bool(ok)))
 
+
+
+def run_pair_case(t, rng):
+    """one random pairwise TV-L1 / TV-L2 registration problem: one outer step (linearise at a random smooth u0, 20 CP
+    iterations from a random dual) on the engine and on the numpy oracle; random strip width of the marching kernel"""
+    from ma_amd import engine as E, synth
+    from ma_amd.drivers import normalize
+    from oracle import prox as px, operators as oo
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    term = ("SAD", "SSD")[int(rng.integers(2))]
+    m = int(rng.choice([9, 17, 40, 62, 63, 64, 65, 126, 127, 150]))
+    n = int(rng.choice([5, 6, 7, 8, 9, 16, 17, 33, 50, 90]))
+    strip = str(rng.choice(["", "4", "6", "8", "16"]))
+    os.environ.pop("CP_TUNE_PW_STRIP", None)
+    if strip:
+        os.environ["CP_TUNE_PW_STRIP"] = strip
+    lam, tau = (4.0, 1.5) if term == "SAD" else (50.0, 4.0)
+    fr = synth.dynamic_test_image(m, n, 2).numpy()
+    if not np.isfinite(fr).all():
+        fr = np.random.default_rng(200 + t).random((2, m, n))
+    R, T = normalize(fr[0]), normalize(fr[1])
+    h = (1.0, 1.0)
+    sigma = (1 - 1e-4) / (8 * tau)
+    K = oo.pairwise_gradient(m, n, h, 2)
+    Gfun = px.SAD_registration if term == "SAD" else px.SSD_registration
+    r2 = np.random.default_rng(300 + t)
+    u0 = 0.5 * synth.smooth_displacement(m, n, 1, amp=1.0).numpy().reshape(-1)
+    v0 = 0.3 * r2.standard_normal(4 * m * n)
+    F = lambda v, c, nargout: px.TV_registration(v, sigma, c, nargout)
+    G = lambda u, c, nargout: Gfun(u, u0, T, R, h, lam, tau, c, nargout)
+    iters = 20
+    xr, yr, phr, dhr = cp_ref(F, G, K, u0, v0, 1.0, tau, sigma, iters)
+    eng = E.Engine(E.MODEL_TV_L1_REG if term == "SAD" else E.MODEL_TV_L2_REG, m, n, lam=lam)
+    eng.set_images(T.reshape(-1, order="F"), R.reshape(-1, order="F"))
+    eng.set_primal(u0)
+    eng.set_dual(v0)
+    eng.linearize()
+    eng.solve(1.0, tau, sigma, iters, 0.0)
+    x, y = eng.primal(), eng.dual()
+    ph, dh = eng.history()
+    eng.close()
+    os.environ.pop("CP_TUNE_PW_STRIP", None)
+    nr = min(ph.shape[0], phr.shape[0])
+    ex, ey = rel(x, xr), rel(y, yr)
+    dp = float(np.max(np.abs(ph[:nr] - phr[:nr]) - 1e-9 * np.abs(phr[:nr])))       # atol as tests/test_gpu_pairwise.py
+    dd = float(np.max(np.abs(dh[:nr] - dhr[:nr]) - 1e-9 * np.abs(dhr[:nr])))
+    ok = ph.shape == phr.shape and ex < 1e-10 and ey < 1e-10 and dp < 1e-10 and dd < 1e-7
+    return dict(case=t, term=term, m=m, n=n, strip=strip, x=ex, y=ey, hist_p=dp, hist_d=dd, ok=bool(ok))
