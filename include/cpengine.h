@@ -238,6 +238,15 @@ int cp_iterate_steps(cp_handle h, int32_t iters);
 int cp_iterate_end(cp_handle h);
 int cp_sync(cp_handle h);
 int cp_kernel_time_ms(cp_handle h, const char *pass, double *ms, int64_t *launches);
+/* diagnostics of the field kernels (no counterpart in the reference):
+ *   cp_dominant_kernel   the name, as rocprofv3 prints it, of the kernel the handle's steady-state iteration spends its time
+ *                        in (template arguments as instantiated for this handle: storage type, boundary rows, K extent, waves
+ *                        per workgroup, ...), NUL-terminated into buf[len]; bench.py keys committed PMC traffic by it.
+ *   cp_handover_fallbacks  number of times, since cp_create, that a wave of an 8-wave kernel gave up on the LDS hand-over
+ *                        between neighbouring waves (time-out) and loaded the neighbour position itself. Results are
+ *                        correct either way; anything but 0 is a performance bug (tests and bench.py assert 0). */
+int cp_dominant_kernel(cp_handle h, char *buf, int32_t len);
+int cp_handover_fallbacks(cp_handle h, int64_t *count);
 /* device-to-device streaming copy rate of this GPU in GB/s (read + write bytes / time, best of `repeats` passes over
  * two buffers of `bytes` each, 8 or 16 bytes per lane, nontemporal): the practical HBM ceiling next to the data sheet's
  * peak. Allocates and frees its own buffers. */
@@ -310,7 +319,10 @@ int cp_mg_power_start(cp_handle h, double *local_sumsq);
  * Calls no hipMalloc / hipFree and no allocating routine; enqueues on hip_stream (NULL: the default stream) and
  * returns WITHOUT synchronising -- dev_sv is valid once the stream has reached that point.
  * Limits: 1 <= k <= 16, m*n <= 2^30; larger inputs are rejected with CP_ERR_UNSUPPORTED.
- * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams or threads) race. */
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams or threads) race.
+ * The caller's current device is left as it was found. The FIRST call per device looks up the array's device address
+ * (hipGetSymbolAddress) and must therefore happen outside a stream capture; every later call only enqueues kernels and
+ * one device-to-device copy. */
 int cp_singular_values_static(int32_t device, const double *dev_field, int32_t m, int32_t n, int32_t k,
                               double *dev_sv, void *hip_stream);
 

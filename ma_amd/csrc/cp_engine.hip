@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -100,6 +101,7 @@ struct cp_engine {
     int fused_ka = 1;    // use the K <= 4 / 8 / 12 instantiations of k_mf_fused_tv (CP_TUNE_FUSED_KA=0: always 16)
     int nblk_fused = 0;  // grid of k_mf_fused_tv / k_mf_fused_curv (2 workgroups per CU resident: two LDS tiles per wave)
     int nblk_y2 = 0;     // grid of k_curv_y2
+    int curv_waves = CP_WAVES, nblk_curv = 0;   // wavefronts (adjacent columns) per workgroup of k_mf_fused_curv and its grid (CP_TUNE_CURV_WAVES = 4 | 8)
     bool curv_fused = false;   // NN-curvature on k_mf_fused_curv + k_curv_y2 (CP_TUNE_CURV_SPLIT=1: the split passes)
     bool linearized = false, has_nu = false, has_images = false;
     hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless cp_set_stream)
@@ -381,6 +383,12 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             h->nblk_var = (int)std::min<long long>((fused2_tasks(h->m, h->nl, 1, h->var_waves) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         }
         h->curv_fused = mf && !var && h->reg == 1;
+        {
+            if (const char *ev = getenv("CP_TUNE_CURV_WAVES")) { if (atoi(ev) == 8) h->curv_waves = 8; if (atoi(ev) == 4) h->curv_waves = CP_WAVES; }
+            if (!h->curv_fused) h->curv_waves = CP_WAVES;
+            const long long t = (long long)fused2_geom(h->m).parts * ((h->nl + h->curv_waves - 1) / h->curv_waves);
+            h->nblk_curv = (int)std::min<long long>((t + 7) / 8 * 8, CP_FUSED_MAXGRID);
+        }
         h->var_fused = var && h->nl == h->d.n_global;
         if (const char *ev = getenv("CP_TUNE_VAR_SPLIT")) { if (atoi(ev) != 0) h->var_fused = false; }
         if (const char *ev = getenv("CP_TUNE_CURV_SPLIT")) { if (atoi(ev) != 0) h->curv_fused = false; }
@@ -889,7 +897,9 @@ static const double *staged_partials(cp_engine *h, int nrows, int *rows, bool sc
     *rows = r2;
     return h->part2;
 }
-static const double *fused_partials(cp_engine *h, int *rows) { return staged_partials(h, (h->reg == 0 && !h->var) ? h->nblk_tv : h->nblk_fused, rows); }
+static const double *fused_partials(cp_engine *h, int *rows) {
+    return staged_partials(h, (h->reg == 0 && !h->var) ? h->nblk_tv : ((h->reg == 1 && !h->var) ? h->nblk_curv : h->nblk_fused), rows);
+}
 
 // iterations n = n0+1 .. n0+count of PDO/chambolle_pock.m:156-179 (state parity follows n)
 static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int check, double tol) {
@@ -959,11 +969,17 @@ static void launch_curv_t(cp_engine *h, const MfParams &P, const double *xp, dou
                           const double *W) {
     const bool neu = (h->d.bc == CP_BC_NEUMANN);
     auto kern = neu ? k_mf_fused_curv<S, true, false> : k_mf_fused_curv<S, false, false>;
-    if (h->K == CP_KMAX) kern = neu ? k_mf_fused_curv<S, true, true> : k_mf_fused_curv<S, false, true>;
+    if (h->curv_waves == 8) {
+        kern = neu ? k_mf_fused_curv<S, true, false, CP_KMAX, 8> : k_mf_fused_curv<S, false, false, CP_KMAX, 8>;
+        if (h->K == CP_KMAX) kern = neu ? k_mf_fused_curv<S, true, true, CP_KMAX, 8> : k_mf_fused_curv<S, false, true, CP_KMAX, 8>;
+        else if (h->K <= 8 && h->fused_ka) kern = neu ? k_mf_fused_curv<S, true, false, 8, 8> : k_mf_fused_curv<S, false, false, 8, 8>;
+        else if (h->K <= 12 && h->fused_ka) kern = neu ? k_mf_fused_curv<S, true, false, 12, 8> : k_mf_fused_curv<S, false, false, 12, 8>;
+    }
+    else if (h->K == CP_KMAX) kern = neu ? k_mf_fused_curv<S, true, true> : k_mf_fused_curv<S, false, true>;
     else if (h->K <= 4 && h->fused_ka) kern = neu ? k_mf_fused_curv<S, true, false, 4> : k_mf_fused_curv<S, false, false, 4>;
     else if (h->K <= 8 && h->fused_ka) kern = neu ? k_mf_fused_curv<S, true, false, 8> : k_mf_fused_curv<S, false, false, 8>;
     else if (h->K <= 12 && h->fused_ka) kern = neu ? k_mf_fused_curv<S, true, false, 12> : k_mf_fused_curv<S, false, false, 12>;
-    hipLaunchKernelGGL(kern, dim3(h->nblk_fused), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
+    hipLaunchKernelGGL(kern, dim3(h->nblk_curv), dim3(64 * h->curv_waves), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
                        (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
 }
 template <typename S>
@@ -1718,6 +1734,71 @@ extern "C" int cp_kernel_time_ms(cp_handle h, const char *pass, double *ms, int6
     *ms = tot;
     if (launches) *launches = (int64_t)(t.used / 2);
     t.used = 0;
+    return CP_OK;
+}
+
+extern "C" int cp_handover_fallbacks(cp_handle h, int64_t *count) {
+    if (!h || !count) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_handover_fallbacks");
+    *count = 0;
+    if (!h->mf) return CP_OK;   // the pairwise kernels have no hand-over
+    HIPCHK(hipSetDevice(h->d.device));
+    int v = 0;
+    HIPCHK(hipMemcpyAsync(&v, &((CpCtrl *)h->ctrl)->hs_fallbacks, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *count = v;
+    return CP_OK;
+}
+
+// the kernel name as rocprofv3 prints it, from the same fields the launchers branch on (launch_fused_t, launch_curv_t,
+// launch_var_fused_t, launch_pw_fused_t): keep the two in step
+extern "C" int cp_dominant_kernel(cp_handle h, char *buf, int32_t len) {
+    if (!h || !buf || len < 1) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_dominant_kernel");
+    const char *S = h->fp32 ? "float" : "double";
+    const char *tf[2] = {"false", "true"};
+    char name[256];
+    const int K = h->K;
+    if (h->mf && !h->var && h->reg == 0) {
+        const bool lin = h->d.bc == CP_BC_LINEAR, n21 = (h->d.flags & CP_FLAG_MFNN_NORM21) != 0;
+        int ka = CP_KMAX, cw = 1, nwv = CP_WAVES;
+        bool fullk = false, ks = false;
+        if (n21) { }
+        else if (K == CP_KMAX) fullk = true;
+        else if (K <= 4 && h->fused_ka) ka = 4;
+        else if (K <= 8 && h->fused_ka) ka = 8;
+        else if (K <= 12 && h->fused_ka) ka = 12;
+        if (h->fused_cw == 2 || h->fused_cw == 4) { cw = h->fused_cw; ka = CP_KMAX; fullk = (K == CP_KMAX); }
+        if (h->fused_waves == 8) {
+            nwv = 8; cw = 1; fullk = (K == CP_KMAX);
+            ka = (K == CP_KMAX) ? CP_KMAX : ((K <= 8 && h->fused_ka) ? 8 : ((K <= 12 && h->fused_ka) ? 12 : CP_KMAX));
+        }
+        if (h->fused_ks) {
+            ks = true; nwv = CP_WAVES; cw = 1; fullk = (K == CP_KMAX);
+            ka = (K == CP_KMAX) ? CP_KMAX : ((K <= 4 && h->fused_ka) ? 4 : ((K <= 8 && h->fused_ka) ? 8 : ((K <= 12 && h->fused_ka) ? 12 : CP_KMAX)));
+        }
+        const bool lin_eff = lin && nwv == CP_WAVES && cw == 1 && !ks;
+        snprintf(name, sizeof name, "k_mf_fused_tv<%s, %s, %s, %d, %s, %d, %d, %s>", S, tf[lin_eff], tf[fullk], ka, tf[n21 && nwv == CP_WAVES && cw == 1 && !ks], cw, nwv, tf[ks]);
+    } else if (h->mf && !h->var) {
+        if (!h->curv_fused) snprintf(name, sizeof name, "k_mf_dual<%s, 0, 1>", S);
+        else {
+            const bool neu = h->d.bc == CP_BC_NEUMANN;
+            int ka = CP_KMAX;
+            if (K != CP_KMAX && h->fused_ka) {
+                if (h->curv_waves == 8) ka = K <= 8 ? 8 : (K <= 12 ? 12 : CP_KMAX);
+                else ka = K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 12 ? 12 : CP_KMAX));
+            }
+            if (h->curv_waves == 8) snprintf(name, sizeof name, "k_mf_fused_curv<%s, %s, %s, %d, 8>", S, tf[neu], tf[K == CP_KMAX], ka);
+            else snprintf(name, sizeof name, "k_mf_fused_curv<%s, %s, %s, %d, 4>", S, tf[neu], tf[K == CP_KMAX], ka);
+        }
+    } else if (h->mf) {
+        if (!h->var_fused) snprintf(name, sizeof name, "k_var_dual<%s, 0, %d>", S, h->reg);
+        else if (h->reg != 0) snprintf(name, sizeof name, "k_var_lazy_curv<%s, %s>", S, tf[h->d.bc == CP_BC_NEUMANN]);
+        else snprintf(name, sizeof name, "k_var_lazy_tv<%s, %s, %d>", S, tf[h->d.bc == CP_BC_LINEAR && h->var_waves != 8], h->var_waves);
+    } else {
+        if (h->pw_split) snprintf(name, sizeof name, "k_pw_dual<%s, 0, %d>", S, h->nc);
+        else if (h->pw_strip > 0) snprintf(name, sizeof name, "k_pw_march<%s, %d>", S, h->gt);
+        else snprintf(name, sizeof name, "k_pw_fused<%s, %d>", S, h->gt);
+    }
+    snprintf(buf, (size_t)len, "%s", name);
     return CP_OK;
 }
 
@@ -2488,22 +2569,18 @@ extern "C" int cp_nn_measure(int32_t device, int32_t version, const double *I, i
 
 // ------------------------------------------------------------------------------------------------
 // Streaming copy: the practical HBM ceiling of this box next to the 8 TB/s of the data sheet (bench.py's
-// roofline.measured_copy_GBps). One element of VEC doubles per lane and step (8 or 16 bytes per lane), grid-stride,
-// nontemporal on both sides -- the access shape of the field kernels (8 B/lane) and the widest one (16 B/lane).
+// roofline.measured_copy_GBps). ONE element of VEC doubles per thread, no loop (the grid covers the buffer), nontemporal on
+// both sides. Round 3 (scratch/bw_copy.hip, profiles/r03_copy_shapes.txt): this shape reaches 6.50 TB/s at 16 B per lane and
+// 5.74 at 8 B per lane; the grid-stride loop of round 2 (one dependent load -> store per thread and trip, 4096 workgroups)
+// reached 4.9 / 5.1 on the same box -- it measured its own loop, not the memory system. The guide's figure for a float4 copy
+// is 6.29 TB/s (/opt/skills/guides/MI355X_MICROARCH.md:36).
 template <int VEC>
-__global__ __launch_bounds__(CP_BLOCK) void k_stream_copy(size_t n, const double *__restrict__ src, double *__restrict__ dst) {
+__global__ __launch_bounds__(CP_BLOCK) void k_stream_copy(size_t nv, const double *__restrict__ src, double *__restrict__ dst) {
     typedef double vec_t __attribute__((ext_vector_type(VEC)));
-    const vec_t *s = reinterpret_cast<const vec_t *>(src);
-    vec_t *d = reinterpret_cast<vec_t *>(dst);
-    const size_t nv = n / VEC, stride = (size_t)gridDim.x * CP_BLOCK;
-    for (size_t q = (size_t)blockIdx.x * CP_BLOCK + threadIdx.x; q < nv; q += stride)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(s + q), d + q);
-}
-template <>
-__global__ __launch_bounds__(CP_BLOCK) void k_stream_copy<1>(size_t n, const double *__restrict__ src, double *__restrict__ dst) {
-    const size_t stride = (size_t)gridDim.x * CP_BLOCK;
-    for (size_t q = (size_t)blockIdx.x * CP_BLOCK + threadIdx.x; q < n; q += stride)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(src + q), dst + q);
+    const size_t q = (size_t)blockIdx.x * CP_BLOCK + threadIdx.x;
+    if (q < nv)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const vec_t *>(src) + q),
+                                    reinterpret_cast<vec_t *>(dst) + q);
 }
 
 extern "C" int cp_stream_copy_gbps(int32_t device, int64_t bytes, int32_t lane_bytes, int32_t repeats, double *gbps) {
@@ -2522,11 +2599,12 @@ extern "C" int cp_stream_copy_gbps(int32_t device, int64_t bytes, int32_t lane_b
         HIPCHK(hipEventCreate(&e0));
         HIPCHK(hipEventCreate(&e1));
         double best = 0.0;
-        const int grid = 256 * 16;
+        const size_t nv = (lane_bytes == 16) ? n / 2 : n;
+        const unsigned grid = (unsigned)((nv + CP_BLOCK - 1) / CP_BLOCK);
         for (int r = 0; r < repeats + 1; ++r) {   // the first pass warms up
             HIPCHK(hipEventRecord(e0, nullptr));
-            if (lane_bytes == 16) hipLaunchKernelGGL((k_stream_copy<2>), dim3(grid), dim3(CP_BLOCK), 0, nullptr, n, a, bq);
-            else hipLaunchKernelGGL((k_stream_copy<1>), dim3(grid), dim3(CP_BLOCK), 0, nullptr, n, a, bq);
+            if (lane_bytes == 16) hipLaunchKernelGGL((k_stream_copy<2>), dim3(grid), dim3(CP_BLOCK), 0, nullptr, nv, a, bq);
+            else hipLaunchKernelGGL((k_stream_copy<1>), dim3(grid), dim3(CP_BLOCK), 0, nullptr, nv, a, bq);
             HIPCHK(hipEventRecord(e1, nullptr));
             HIPCHK(hipEventSynchronize(e1));
             float ms = 0.f;
@@ -2555,7 +2633,7 @@ extern "C" int cp_stream_copy_gbps(int32_t device, int64_t bytes, int32_t lane_b
 #define CP_NA_SCRATCH (CP_NA_PART + 16 + 256 + 256 + 256)     // + eigenvalues, rotation out, identity, rotation in
 static __device__ __align__(256) double scratch[CP_NA_SCRATCH];   // 3.3 MB on every GPU the library runs on
 #define CP_NA_MAXDEV 64
-static double *g_na_ptr[CP_NA_MAXDEV];                        // device address of `scratch` per device (0: not looked up yet)
+static std::atomic<double *> g_na_ptr[CP_NA_MAXDEV];           // device address of `scratch` per device (null: not looked up yet)
 
 __global__ void k_na_identity(double *ident) {
     const int t = threadIdx.x;
@@ -2583,14 +2661,24 @@ extern "C" int cp_singular_values_static(int32_t device, const double *dev_field
         CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_singular_values_static: k = %d exceeds the static scratch (1..%d images)", k, CP_KMAX);
     if ((long long)m * n > (1LL << 30))
         CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_singular_values_static: %d x %d pixels exceed the limit of 2^30 per image", m, n);
-    HIPCHK(hipSetDevice(device));
-    if (!g_na_ptr[device]) {   // once per device, with that device current: every GPU holds its own copy of the array
+    // the caller's current device is restored on every path out (a serving loop must not find its device changed)
+    struct DeviceGuard {
+        int prev = -1;
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } guard;
+    int cur = -1;
+    HIPCHK(hipGetDevice(&cur));
+    if (cur != device) { HIPCHK(hipSetDevice(device)); guard.prev = cur; }
+    double *base = g_na_ptr[device].load(std::memory_order_acquire);
+    if (!base) {   // once per device, with that device current: every GPU holds its own copy of the array. Two threads that
+                   // race here look up the same address and store the same value. This first call per device must happen
+                   // OUTSIDE a stream capture (hipGetSymbolAddress is not a stream operation); later calls only enqueue.
         double *ptr = nullptr;
         HIPCHK(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
         if (!ptr) CP_FAIL(CP_ERR_DEVICE, "cpengine:device hipGetSymbolAddress(scratch) returned a null address");
-        g_na_ptr[device] = ptr;
+        g_na_ptr[device].store(ptr, std::memory_order_release);
+        base = ptr;
     }
-    double *base = g_na_ptr[device];
     double *part = base, *svout = base + CP_NA_PART, *vout = svout + 16, *ident = svout + 16 + 256, *vin = ident + 256;
     hipStream_t st = (hipStream_t)hip_stream;
     MfParams P;

@@ -24,7 +24,8 @@
 struct CpCtrl {
     int stop;          // set by the stop rule; every later kernel of the solve returns immediately
     int stop_iter;     // i at which the rule fired
-    int pad0, pad1;
+    int hs_fallbacks;  // hand-over time-outs / fall-backs of the 8-wave kernels since cp_create (hs_report; must stay 0)
+    int pad1;
     double c[2][2];    // pending mean offsets of the two x buffers: true u = stored - c[buf][comp] (split passes)
     double cn[2];      // mean of the next un-projected u, known before the fused pass runs (see k_mf_fused_tv)
     double nu;         // radius of the nuclear-norm ball

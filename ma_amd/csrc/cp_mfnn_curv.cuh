@@ -24,13 +24,15 @@
 // columns per workgroup, no workgroup barrier in the loop. y2_n at (i+1, j) is lane+1's own value (lane 63: the value
 // lane 0 loaded one step earlier, through LDS; at the top of a part a load in lane 63 alone), at (i-1, j) one
 // element-shifted load, at (i, j-1) and (i, j+1) the lines the neighbouring waves stream.
-template <typename S, bool NEUMANN, bool FULLK, int KA = CP_KMAX>
-__global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_curv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
+// Round 3: (i-1, j) is lane - 1's own value (cross-lane shift, lane_shr1) and one load in the segment's first lane instead
+// of an element-shifted wave-wide load that straddles five lines; NWV = 8 adjacent columns per workgroup (one workgroup per
+// CU) halves the (i, j +- 1) lines that belong to another workgroup.
+template <typename S, bool NEUMANN, bool FULLK, int KA = CP_KMAX, int NWV = CP_WAVES>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_curv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
                                                                 const S *__restrict__ pin, S *__restrict__ pout,
                                                                 const S *__restrict__ g, const S *__restrict__ b,
                                                                 const double *__restrict__ W,
                                                                 const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
-    constexpr int NWV = CP_WAVES;
     __shared__ double tiles[NWV * 2 * 16 * CP_TS];
     __shared__ double Wl[CP_KMAX * CP_KMAX];
     __shared__ double carry_all[NWV * 2 * CP_KMAX * 2];   // [wave][step parity][image][y2 component] of lane 0
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_curv(MfParams P, const
 
     const Fused2Geom GM = fused2_geom(m);
     const int ntasks = GM.parts * ((P.nl + NWV - 1) / NWV);
+    const unsigned off_l0 = (lane == 0) ? 0u : 0xFFFFFFFFu;       // only the segment's first lane loads (i-1, j)
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
         const int cg = task / GM.parts, pt = task - cg * GM.parts;
         const int j = cg * NWV + wave;
@@ -105,7 +108,13 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_curv(MfParams P, const
                 for (int c = 0; c < 2; ++c) {
                     const S *f = y2k + (size_t)c * fs;
                     const double w0 = ldo(f, off);
+#if CP_FUSED_SHF
+                    const double wim0 = bld<S>(mk_rsrc(f), (off - ES) | off_l0);   // lanes 1..63: out of range, dropped
+                    const double wsh = lane_shr1<double>(w0);         // evaluated by every lane, before the select
+                    const double wim = (lane == 0) ? wim0 : wsh;
+#else
                     const double wim = ldo(f, off, -(int)ES);
+#endif
                     const double wjm = ldo(f, off - mb), wjp = ldo(f, off + mb);
                     double wip = __shfl(w0, lane + 1);
                     if (from_carry) wip = cin[2 * k + c];
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(CP_BLOCK, 2) void k_mf_fused_curv(MfParams P, const
             st[CP_NSCAL + 256 + e] = acc2[r];
         }
         __syncthreads();
-        for (int e = tid; e < CP_PSTRIDE; e += CP_BLOCK) {
+        for (int e = tid; e < CP_PSTRIDE; e += NWV * 64) {
             const bool is_max = (e >= CP_NSUM && e < CP_NSCAL);
             double v = tiles[e];
 #pragma unroll

@@ -30,19 +30,53 @@ struct PrimalAt { double ux, uy, uxo, uyo, wx, wy, y1, gx, gy, v0, v1, v2, v3; }
 // what one evaluation loads: y1, grad T, the four y2 components at the position and at their adjoint neighbours, u_{n-1}
 template <typename S>
 struct ImgLoads { S y1, gx, gy, v0, v1, v2, v3, w0m, w1m, w2m, w3m, uxo, uyo, l0, l1, l2, l3; };   // as stored (see bld_raw)
-template <typename S, bool LINEAR>
+// Measured (round 3, profiles/r03_exp_reads.txt, r03_exp_handover.txt): dropping the (i-1, j) loads altogether saves 1.2 GB of
+// reads and 0.5 ms per launch of k_mf_fused_tv at 4096^2 x 16, but SHF = 1 -- lanes 1..63 from lane - 1, the first lane of the
+// segment still loads -- saves neither (8.59 vs 8.61 ms, FETCH_SIZE equal): the cost is the line under the segment, which that
+// one lane still fetches, not the element-shifted access. k_mf_fused_curv was 4 % slower with it. Off by default.
+#ifndef CP_FUSED_SHF
+#define CP_FUSED_SHF 0
+#endif
+// value of lane - 1 (lane 0 receives 0): one v_mov_b32 dpp wave_shr:1 per dword, no LDS traffic. Must be called where every
+// lane of the wave is active (a DPP read from a disabled lane delivers nothing): never inside one arm of a ?: on a
+// lane-dependent condition -- assign the result to a variable first. The empty volatile asm keeps the moves where the call
+// is, so that a later select on a lane-dependent condition cannot pull them into its arm either.
+template <typename S>
+__device__ __forceinline__ S lane_shr1(S v) {
+    if constexpr (sizeof(S) == 8) {
+        int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+        int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        return __hiloint2double(hi, lo);
+    } else {
+        int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false);
+        asm volatile("" : "+v"(r));
+        return __builtin_bit_cast(float, r);
+    }
+}
+// SHF (round 3; lanes = consecutive rows, evaluated by every lane of the wave): the Dx components of y2 at (i-1, j) are the
+// values lane - 1 loaded for its own row, so they come from a cross-lane shift; only the first lane of the segment loads
+// its (i-1, j) -- the other lanes carry an offset beyond the descriptor's range and the range check drops them. The two
+// element-shifted wave-wide loads this replaces straddled five lines instead of four: 1.2 GB of reads and 0.5 ms per launch
+// at 4096^2 x 16 (profiles/r03_exp_reads.txt).
+template <typename S, bool LINEAR, bool SHF = false>
 __device__ __forceinline__ void img_load(const MfParams &P, int i, int jg, unsigned oc, unsigned fsb, const ImgRsrc &R,
-                                         ImgLoads<S> &q) {
+                                         ImgLoads<S> &q, int li = 0) {
     constexpr unsigned ES = (unsigned)sizeof(S);
     const int m = P.m;
     const unsigned oim = oc - ES, ojm = oc - ES * (unsigned)m;        // (i-1, j) and (i, j-1): inside the allocation (halo column)
     q.y1 = bld_raw<S>(R.y1, oc);
     q.gx = bld_raw<S>(R.g, oc); q.gy = bld_raw<S>(R.g, oc, fsb);
     q.v0 = bld_raw<S>(R.y2a, oc); q.v1 = bld_raw<S>(R.y2a, oc, fsb); q.v2 = bld_raw<S>(R.y2b, oc); q.v3 = bld_raw<S>(R.y2b, oc, fsb);
-    q.w0m = bld_raw<S>(R.y2a, oim); q.w2m = bld_raw<S>(R.y2b, oim);                      // Dx components: adjoint along i
+    const unsigned oim_l = (!SHF || li == 0) ? oim : 0xFFFFFFFFu;
+    q.w0m = bld_raw<S>(R.y2a, oim_l); q.w2m = bld_raw<S>(R.y2b, oim_l);                  // Dx components: adjoint along i
     q.w1m = bld_raw<S>(R.y2a, ojm, fsb); q.w3m = bld_raw<S>(R.y2b, ojm, fsb);            // Dy components: adjoint along j
     q.uxo = bld_raw<S>(R.u, oc);
     q.uyo = bld_raw<S>(R.u, oc, fsb);
+#ifdef CP_EXP   // timing / traffic experiments only (results wrong): 1 no (i, j-1) loads, 2 no (i-1, j) loads
+    if (CP_EXP & 1) { q.w1m = q.v1; q.w3m = q.v3; }
+    if (CP_EXP & 2) { q.w0m = q.v0; q.w2m = q.v2; }
+#endif
     q.l0 = q.l1 = q.l2 = q.l3 = (S)0;
     if (LINEAR) {
         const unsigned oli = oc + ES * (unsigned)((m - 1) - i);
@@ -52,15 +86,21 @@ __device__ __forceinline__ void img_load(const MfParams &P, int i, int jg, unsig
         q.l1 = bld_raw<S>(R.y2a, olj, fsb); q.l3 = bld_raw<S>(R.y2b, olj, fsb);
     }
 }
-template <typename S, bool LINEAR>
+template <typename S, bool LINEAR, bool SHF = false>
 __device__ __forceinline__ void img_eval(const MfParams &P, int i, int jg, const ImgLoads<S> &q, double cnx, double cny,
-                                         PrimalAt &r) {
+                                         PrimalAt &r, int li = 0) {
     const int m = P.m;
+    S w0m = q.w0m, w2m = q.w2m;
+    if (SHF) {
+        const S s0 = lane_shr1<S>(q.v0), s2 = lane_shr1<S>(q.v2);
+        w0m = (li == 0) ? q.w0m : s0;
+        w2m = (li == 0) ? q.w2m : s2;
+    }
     r.y1 = (double)q.y1; r.gx = (double)q.gx; r.gy = (double)q.gy; r.v0 = (double)q.v0; r.v1 = (double)q.v1; r.v2 = (double)q.v2;
     r.v3 = (double)q.v3; r.uxo = (double)q.uxo; r.uyo = (double)q.uyo;
-    const double a0 = fwd_diff_adj(r.v0, (i >= 1) ? (double)q.w0m : 0.0, (double)q.l0, i, m, LINEAR, P.inv_h1);
+    const double a0 = fwd_diff_adj(r.v0, (i >= 1) ? (double)w0m : 0.0, (double)q.l0, i, m, LINEAR, P.inv_h1);
     const double a1 = fwd_diff_adj(r.v1, (jg >= 1) ? (double)q.w1m : 0.0, (double)q.l1, jg, P.n_global, LINEAR, P.inv_h2);
-    const double a2 = fwd_diff_adj(r.v2, (i >= 1) ? (double)q.w2m : 0.0, (double)q.l2, i, m, LINEAR, P.inv_h1);
+    const double a2 = fwd_diff_adj(r.v2, (i >= 1) ? (double)w2m : 0.0, (double)q.l2, i, m, LINEAR, P.inv_h1);
     const double a3 = fwd_diff_adj(r.v3, (jg >= 1) ? (double)q.w3m : 0.0, (double)q.l3, jg, P.n_global, LINEAR, P.inv_h2);
     const double vux = -r.gx * r.y1 + (a0 + a1);
     const double vuy = -r.gy * r.y1 + (a2 + a3);
@@ -219,28 +259,80 @@ __host__ __device__ inline long long fused2_tasks(int m, int nl, int cw = 1, int
 #ifndef CP_FUSED_HS
 #define CP_FUSED_HS 1
 #endif
-__device__ __forceinline__ void hs_give(double *slot, int *ack, int *pub, int n, int lane, double a, double b, double c,
-                                        double d) {
-    volatile int *vack = ack;
-    while (*vack < n - 1) __builtin_amdgcn_s_sleep(1);
-    volatile double *vs = slot;
-    vs[lane] = a; vs[64 + lane] = b; vs[128 + lane] = c; vs[192 + lane] = d;
-    if (lane == 0) *(volatile int *)pub = n;
+#ifndef CP_HS_MAXPOLL
+#define CP_HS_MAXPOLL (1 << 22)    // ~0.1 s of s_sleep(1) polls
+#endif
+// The order "values, then counter" / "counter, then values" is what the protocol needs, from two sides:
+//   * the hardware: DS instructions of one wave execute in program order (see above);
+//   * the compiler: the accesses are volatile AND separated by __atomic_signal_fence(seq_cst), which forbids the compiler
+//     to move any memory access across it and emits no instruction.
+// Round 3 measured the alternative the memory model offers, a workgroup-scope release / acquire fence restricted to the LDS
+// address space (__builtin_amdgcn_fence(..., "workgroup", "local"), CP_HS_FENCE=1): it waits for every DS instruction of
+// the wave in flight (lgkmcnt(0)), the tile reads of the Gram step included -- 8.59 ms instead of 8.24 per launch at
+// 4096^2 x 16 on the same box (profiles/r03_exp_handover.txt) -- so the compiler-only fence stays the default.
+#ifndef CP_HS_FENCE
+#define CP_HS_FENCE 0
+#endif
+__device__ __forceinline__ void hs_release() {
+#if CP_HS_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+#else
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#endif
 }
-__device__ __forceinline__ bool hs_take(const double *slot, int *pub, int *ack, int n, int lane, double &a, double &b,
-                                        double &c, double &d) {
-    volatile int *vpub = pub;
+__device__ __forceinline__ void hs_acquire() {
+#if CP_HS_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#endif
+}
+// Both waits are bounded (CP_HS_MAXPOLL). A giver that times out marks the pair broken and never writes the slot again (the
+// consumer may still be reading result n-1); a consumer that finds the pair broken, or times out, acknowledges and reports
+// false -- its caller loads and evaluates the position itself, always correct. Every such event is counted (return value of
+// hs_give, !hs_take) and added to CpCtrl::hs_fallbacks at the end of the kernel: cp_handover_fallbacks() must read 0.
+// The slot and flag pointers carry the LDS address space in their type (no generic pointers whose address space the compiler
+// would have to infer: one instantiation failed in the backend with a flat-pointer aperture test otherwise).
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __forceinline__ int hs_give(lds_double *slot, lds_int *ack, lds_int *pub, lds_int *broken, int n, int lane, double a,
+                                       double b, double c, double d) {
+    volatile lds_int *vack = ack, *vbr = broken;
+    if (*vbr) return 0;
+    for (int polls = 0; *vack < n - 1; ++polls) {
+        if (polls > CP_HS_MAXPOLL) {
+            if (lane == 0) *vbr = 1;
+            return 1;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    hs_acquire();                       // the consumer's reads of result n-1 precede its ack
+    volatile lds_double *vs = slot;
+    vs[lane] = a; vs[64 + lane] = b; vs[128 + lane] = c; vs[192 + lane] = d;
+    hs_release();
+    if (lane == 0) *(volatile lds_int *)pub = n;
+    return 0;
+}
+__device__ __forceinline__ bool hs_take(const lds_double *slot, lds_int *pub, lds_int *ack, lds_int *broken, int n, int lane,
+                                        double &a, double &b, double &c, double &d) {
+    volatile lds_int *vpub = pub, *vbr = broken;
     bool ok = true;
     for (int polls = 0; *vpub < n; ++polls) {
-        if (polls > (1 << 22)) { ok = false; break; }
+        if (polls > CP_HS_MAXPOLL || *vbr) { ok = false; break; }
         __builtin_amdgcn_s_sleep(1);
     }
     if (ok) {
-        const volatile double *vs = slot;
+        hs_acquire();
+        const volatile lds_double *vs = slot;
         a = vs[lane]; b = vs[64 + lane]; c = vs[128 + lane]; d = vs[192 + lane];
+        hs_release();
     }
-    if (lane == 0) *(volatile int *)ack = n;
+    if (lane == 0) *(volatile lds_int *)ack = n;
     return ok;
+}
+// end of a kernel that used the hand-over: add this wave's fall-backs to the handle's counter
+__device__ __forceinline__ void hs_report(const CpCtrl *ctrl, int fallbacks, int lane) {
+    if (fallbacks != 0 && lane == 0) atomicAdd(const_cast<int *>(&ctrl->hs_fallbacks), fallbacks);
 }
 
 // KA = extent of the per-pixel image arrays (4, 8, 12 or 16 >= K): phase 1 loads, multiplies by W and stores KA images, so
@@ -272,8 +364,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
     // without it 9.20-9.26 ms and 57.3 GB (37.9 GB read: neighbouring waves miss the same line at the same moment and both
     // fetch it); 4 waves with it 9.31-9.63 ms, 51.8 GB; 8 waves without it 10.2-10.6 ms
     constexpr bool HS = (CP_FUSED_HS != 0) && !LINEAR && CW == 1 && NWV == 8;
+    constexpr bool SHF = (CP_FUSED_SHF != 0) && CW == 1;   // (i-1, j) from lane - 1 (img_load)
     __shared__ double xch_all[HS ? (NWV - 1) * 256 : 1];   // hand-over slots, one per pair of neighbouring waves
-    __shared__ int hs_flags[2 * NWV];                       // pub[wave], ack[wave]
+    __shared__ int hs_flags[3 * NWV];                       // pub[wave], ack[wave], broken[wave]
     const int stopped = ctrl->stop;
     const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -288,11 +381,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
     if (KA < CP_KMAX) {
         for (int k = KA; k < CP_KMAX; ++k) tileA[k * CP_TS + lane] = 0.0;
     }
-    if (tid < 2 * NWV) hs_flags[tid] = 0;
+    if (tid < 3 * NWV) hs_flags[tid] = 0;
     __syncthreads();
-    int *fl = hs_flags;
-    double *xl = xch_all + (HS && wave > 0 ? (wave - 1) * 256 : 0);       // slot this wave gives into (to wave - 1)
-    const double *xr = xch_all + (HS && wave < NWV - 1 ? wave * 256 : 0);  // slot this wave takes from (wave + 1)
+    lds_int *fl = (lds_int *)hs_flags;
+    int hs_fb = 0;                                                         // hand-over fall-backs of this wave (hs_report)
+    lds_double *xl = (lds_double *)xch_all + (HS && wave > 0 ? (wave - 1) * 256 : 0);       // slot this wave gives into (to wave - 1)
+    const lds_double *xr = (lds_double *)xch_all + (HS && wave < NWV - 1 ? wave * 256 : 0);  // slot this wave takes from (wave + 1)
     int pseq = 0, cseq = 0;
     const double sigma = P.sigma, tau = P.tau, theta = P.theta, inv_sigma = 1.0 / P.sigma;
     const S *y3in = pin + 5 * (size_t)K * fs;
@@ -364,29 +458,33 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
                 const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
                 PrimalAt r0, rj;
                 ImgLoads<S> q0, qj;
-                img_load<S, LINEAR>(P, i, jg, off, fsb, R, q0);
+                img_load<S, LINEAR, SHF>(P, i, jg, off, fsb, R, q0, li);
                 // (i, j+1): the wave of the next column computes exactly this as its own-pixel result and hands it over through
                 // LDS (hs_take below); only a wave without such a neighbour -- the last of the workgroup, the last column of a
                 // slab -- loads and evaluates the position itself. Evaluated by every lane (no lane-dependent branch).
-                if (!hs_c) img_load<S, LINEAR>(P, i, jg + oj, offj, fsb, R, qj);
+#ifdef CP_EXP   // 4: no (i, j+1) evaluation from memory at all
+                if (CP_EXP & 4) qj = q0; else
+#endif
+                if (!hs_c) img_load<S, LINEAR, SHF>(P, i, jg + oj, offj, fsb, R, qj, li);
                 const S bb_raw = bld_raw_stream<S>(mk_rsrc(b + (size_t)k * fs), off);
                 // fp32 storage: keep the float -> double conversions behind the whole group of loads (left alone, the compiler
                 // converts each value as it arrives into the register the next load is waiting for: one load in flight)
                 if (sizeof(S) == 4) __builtin_amdgcn_sched_barrier(0);
                 const double bb = (double)bb_raw;
-                img_eval<S, LINEAR>(P, i, jg, q0, cnx, cny, r0);
+                img_eval<S, LINEAR, SHF>(P, i, jg, q0, cnx, cny, r0, li);
                 if (HS) {
-                    if (hs_p) hs_give(xl, fl + NWV + (wave - 1), fl + wave, ++pseq, lane, r0.ux, r0.uy, r0.uxo, r0.uyo);
+                    if (hs_p) hs_fb += hs_give(xl, fl + NWV + (wave - 1), fl + wave, fl + 2 * NWV + wave, ++pseq, lane, r0.ux, r0.uy, r0.uxo, r0.uyo);
                     if (hs_c) {
-                        if (!hs_take(xr, fl + (wave + 1), fl + NWV + wave, ++cseq, lane, rj.ux, rj.uy, rj.uxo, rj.uyo)) {
-                            img_load<S, LINEAR>(P, i, jg + oj, offj, fsb, R, qj);      // never in practice: see hs_take
-                            img_eval<S, LINEAR>(P, i, jg + oj, qj, cnx, cny, rj);
+                        if (!hs_take(xr, fl + (wave + 1), fl + NWV + wave, fl + 2 * NWV + (wave + 1), ++cseq, lane, rj.ux, rj.uy, rj.uxo, rj.uyo)) {
+                            ++hs_fb;
+                            img_load<S, LINEAR, SHF>(P, i, jg + oj, offj, fsb, R, qj, li);      // never in practice: see hs_take
+                            img_eval<S, LINEAR, SHF>(P, i, jg + oj, qj, cnx, cny, rj, li);
                         }
                     } else {
-                        img_eval<S, LINEAR>(P, i, jg + oj, qj, cnx, cny, rj);
+                        img_eval<S, LINEAR, SHF>(P, i, jg + oj, qj, cnx, cny, rj, li);
                     }
                 } else {
-                    img_eval<S, LINEAR>(P, i, jg + oj, qj, cnx, cny, rj);
+                    img_eval<S, LINEAR, SHF>(P, i, jg + oj, qj, cnx, cny, rj, li);
                 }
                 const double ux = r0.ux, uy = r0.uy, uxo_ = r0.uxo, uyo_ = r0.uyo, wx = r0.wx, wy = r0.wy;
                 const double gx = r0.gx, gy = r0.gy, y1 = r0.y1, v0 = r0.v0, v1 = r0.v1, v2 = r0.v2, v3 = r0.v3;
@@ -467,6 +565,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
             wave_lds_sync();   // hand-over and tiles of this step are complete before the next step touches them
         }
     }
+    if (HS) hs_report(ctrl, hs_fb, lane);
     if (KS && wave != 0) { acc1 = double4_t{0.0, 0.0, 0.0, 0.0}; acc2 = double4_t{0.0, 0.0, 0.0, 0.0}; }   // phase 1 ran four times
     double *out = part + (size_t)blockIdx.x * CP_PSTRIDE;
     {

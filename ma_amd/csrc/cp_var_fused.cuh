@@ -85,16 +85,17 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_var_lazy_tv(MfPa
     __shared__ double stage_all[NWV * CP_NSCAL];
     constexpr bool HS = (CP_FUSED_HS != 0) && !LINEAR && NWV == 8;
     __shared__ double xch_all[HS ? (NWV - 1) * 256 : 1];
-    __shared__ int hs_flags[2 * NWV];
+    __shared__ int hs_flags[3 * NWV];
     const int stopped = ctrl->stop;
     const double cnx = ctrl->cn[0], cny = ctrl->cn[1];
     if (stopped) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 2 * NWV) hs_flags[tid] = 0;
+    if (tid < 3 * NWV) hs_flags[tid] = 0;
     __syncthreads();
-    int *fl = hs_flags;
-    double *xl = xch_all + (HS && wave > 0 ? (wave - 1) * 256 : 0);
-    const double *xr = xch_all + (HS && wave < NWV - 1 ? wave * 256 : 0);
+    lds_int *fl = (lds_int *)hs_flags;
+    int hs_fb = 0;
+    lds_double *xl = (lds_double *)xch_all + (HS && wave > 0 ? (wave - 1) * 256 : 0);
+    const lds_double *xr = (lds_double *)xch_all + (HS && wave < NWV - 1 ? wave * 256 : 0);
     int pseq = 0, cseq = 0;
     double *carry = carry_all + wave * CP_VAR_KMAX * 4;
     const int K = P.K, m = P.m;
@@ -165,9 +166,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_var_lazy_tv(MfPa
                 var_eval<S, LINEAR>(P, i, jg, q0, ab, cnx, cny, ux, uy, wx, wy);
                 double uxoj = 0.0, uyoj = 0.0;
                 if (HS) {
-                    if (hs_p) hs_give(xl, fl + NWV + (wave - 1), fl + wave, ++pseq, lane, ux, uy, q0.uxo, q0.uyo);
+                    if (hs_p) hs_fb += hs_give(xl, fl + NWV + (wave - 1), fl + wave, fl + 2 * NWV + wave, ++pseq, lane, ux, uy, q0.uxo, q0.uyo);
                     if (hs_c) {
-                        if (!hs_take(xr, fl + (wave + 1), fl + NWV + wave, ++cseq, lane, uxj, uyj, uxoj, uyoj)) {
+                        if (!hs_take(xr, fl + (wave + 1), fl + NWV + wave, fl + 2 * NWV + (wave + 1), ++cseq, lane, uxj, uyj, uxoj, uyoj)) {
+                            ++hs_fb;
                             var_load<S, LINEAR>(P, i, jg + oj, offj, fsb, R, qj);         // never in practice: see hs_take
                             var_eval<S, LINEAR>(P, i, jg + oj, qj, abj, cnx, cny, uxj, uyj, wd0, wd1);
                             uxoj = qj.uxo; uyoj = qj.uyo;
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_var_lazy_tv(MfPa
             wave_lds_sync();   // hand-over of this step is complete before the next step reads it
         }
     }
+    if (HS) hs_report(ctrl, hs_fb, lane);
     {
         double *st = stage_all + wave * CP_NSCAL;
 #pragma unroll

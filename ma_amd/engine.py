@@ -77,6 +77,8 @@ def _load():
         "cp_sync": [vp],
         "cp_kernel_time_ms": [vp, C.c_char_p, dp, C.POINTER(C.c_int64)],
         "cp_set_stream": [vp, vp],
+        "cp_dominant_kernel": [vp, C.c_char_p, C.c_int32],
+        "cp_handover_fallbacks": [vp, C.POINTER(C.c_int64)],
         "cp_mg_halo_pack": [vp, C.c_int, C.c_int, C.c_int, vp],
         "cp_mg_halo_unpack": [vp, C.c_int, C.c_int, C.c_int, vp],
         "cp_mg_state_pack": [vp, C.c_int, C.c_int, vp, vp],
@@ -128,7 +130,7 @@ EXPORTED = ["cp_last_error", "cp_version", "cp_create", "cp_destroy", "cp_set_im
             "cp_linearize", "cp_get_linearization", "cp_set_linearization", "cp_apply_A", "cp_apply_At", "cp_set_nu", "cp_singular_values", "cp_norm_estimate", "cp_solve",
             "cp_get_result", "cp_get_history", "cp_get_primal", "cp_get_dual", "cp_get_images", "cp_prolong",
             "cp_downsample", "cp_iterate", "cp_iterate_begin", "cp_iterate_steps", "cp_iterate_end", "cp_sync",
-            "cp_kernel_time_ms", "cp_set_stream", "cp_mg_partial_len",
+            "cp_kernel_time_ms", "cp_set_stream", "cp_dominant_kernel", "cp_handover_fallbacks", "cp_mg_partial_len",
             "cp_mg_halo_len", "cp_mg_halo_pack", "cp_mg_halo_unpack", "cp_mg_state_pack", "cp_mg_state_unpack", "cp_mg_begin", "cp_mg_stage", "cp_mg_end",
             "cp_mg_stop_state", "cp_mg_gram", "cp_mg_power_start", "cp_singular_values_static", "cp_stream_copy_gbps", "cp_evaluate_displacement",
             "cp_nuclear_norm", "cp_nn_measure", "cp_landmark_transform", "cp_landmark_accuracy"]
@@ -380,6 +382,18 @@ class Engine:
         n = C.c_int64()
         _chk(lib.cp_kernel_time_ms(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def dominant_kernel(self):
+        """name of the kernel the steady-state iteration spends its time in, as rocprofv3 prints it (cp_dominant_kernel)"""
+        buf = C.create_string_buffer(256)
+        _chk(lib.cp_dominant_kernel(self._h, buf, 256))
+        return buf.value.decode()
+
+    def handover_fallbacks(self):
+        """hand-over time-outs of the 8-wave kernels since the handle was created (cp_handover_fallbacks); must be 0"""
+        n = C.c_int64()
+        _chk(lib.cp_handover_fallbacks(self._h, C.byref(n)))
+        return n.value
 
 
 def singular_values_static(device, field_ptr, m, n, k, sv_ptr, stream_ptr=0):

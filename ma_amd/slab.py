@@ -91,5 +91,14 @@ class SlabSolver:
     def kernel_times(self):
         return {name: self.eng.kernel_time_ms(name) for name in ("dual", "eig", "primal", "fin", "iterate")}
 
+    def _handle(self):
+        return getattr(self.eng, "eng", self.eng)        # MultiGpuEngine wraps the rank's Engine
+
+    def dominant_kernel(self):
+        return self._handle().dominant_kernel()
+
+    def handover_fallbacks(self):
+        return self._handle().handover_fallbacks()
+
     def close(self):
         self.eng.close()

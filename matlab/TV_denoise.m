@@ -2,15 +2,15 @@ function [res1, res2, res3] = TV_denoise(v, sigma, conjugate_flag)
 % Same signature as Primal Dual Optimization/TV_denoise.m:1.
 %   F = TV_denoise([], sigma)            operator struct for chambolle_pock (engine path); replaces the closure
 %                                     F = @(v, c_flag) TV_denoise(v, sigma, c_flag)
-%   [..] = TV_denoise(v, sigma, flag)    numeric v: the original function, kept as TV_denoise_matlab.m
+%   [..] = TV_denoise(v, sigma, flag)    numeric v: the reference's own TV_denoise.m (cp_call_shadowed)
 if isempty(v)
     res1 = struct('type', 'TV_denoise', 'sigma', sigma);
     return
 end
 if nargin < 3, conjugate_flag = false; end
 if nargout == 3
-    [res1, res2, res3] = TV_denoise_matlab(v, sigma, conjugate_flag);
+    [res1, res2, res3] = cp_call_shadowed('TV_denoise', v, sigma, conjugate_flag);
 else
-    [res1, res2] = TV_denoise_matlab(v, sigma, conjugate_flag);
+    [res1, res2] = cp_call_shadowed('TV_denoise', v, sigma, conjugate_flag);
 end
 end

@@ -3,7 +3,7 @@ function [x_star, y_star, primal_history, dual_history] = ...
 % Same signature, defaults and outputs as Primal Dual Optimization/chambolle_pock.m:1-2,54-70.
 %   F, G operator structs (TV_registration([], sigma), SAD_registration([], u0, T, R, h, lambda, tau), ...):
 %       the whole iteration runs in libcpengine.so through cp_mex; histories come back with the reference's columns.
-%   F, G function handles: arbitrary closures cannot be fused; the original loop runs (kept as chambolle_pock_matlab.m).
+%   F, G function handles: arbitrary closures cannot be fused; the original loop runs (the reference's own chambolle_pock.m, found on the path by cp_call_shadowed).
 if ~isstruct(F) || ~isstruct(G)
     args = {F, G, K, x0, y0};
     if nargin >= 6,  args{end + 1} = theta;   end
@@ -11,7 +11,7 @@ if ~isstruct(F) || ~isstruct(G)
     if nargin >= 8,  args{end + 1} = sigma;   end
     if nargin >= 9,  args{end + 1} = maxIter; end
     if nargin >= 10, args{end + 1} = tol;     end
-    [x_star, y_star, primal_history, dual_history] = chambolle_pock_matlab(args{:});
+    [x_star, y_star, primal_history, dual_history] = cp_call_shadowed('chambolle_pock', args{:});
     return
 end
 c = cp_const();

@@ -316,6 +316,14 @@ void dispatch(const char *cmd, int nlhs, mxArray *plhs[], int nrhs, const mxArra
     } else if (!strcmp(cmd, "downsample")) {             // cp_mex('downsample', h_fine, h_coarse)
         need(nrhs >= 3, "cp_mex('downsample', h_fine, h_coarse)");
         check(cp_downsample(h, handle_of(prhs[2])));
+    } else if (!strcmp(cmd, "dominant_kernel")) {        // name = cp_mex('dominant_kernel', h)
+        char name[256];
+        check(cp_dominant_kernel(h, name, (int32_t)sizeof name));
+        plhs[0] = mxCreateString(name);
+    } else if (!strcmp(cmd, "handover_fallbacks")) {     // n = cp_mex('handover_fallbacks', h): must be 0
+        int64_t cnt = 0;
+        check(cp_handover_fallbacks(h, &cnt));
+        plhs[0] = mxCreateDoubleScalar((double)cnt);
     } else if (!strcmp(cmd, "iterate")) {                // cp_mex('iterate', h, theta, tau, sigma, iters): no stop rule, asynchronous
         need(nrhs >= 6, "cp_mex('iterate', h, theta, tau, sigma, iters)");
         check(cp_iterate(h, scalar(prhs[2], "theta"), scalar(prhs[3], "tau"), scalar(prhs[4], "sigma"), (int32_t)scalar(prhs[5], "iters")));

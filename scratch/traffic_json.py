@@ -26,7 +26,7 @@ while args:
     args = args[4:]
     fe, wr = collect(d, "pmc_fetch"), collect(d, "pmc_write")
     for kern in fe:
-        if not any(t in kern for t in ("k_mf_fused", "k_mf_dual", "k_mf_primal", "k_curv_", "k_var_", "k_pw_march")) or kern not in wr:
+        if not any(t in kern for t in ("k_mf_fused", "k_mf_dual", "k_mf_primal", "k_curv_", "k_var_", "k_pw_march", "k_pw_fused")) or kern not in wr:
             continue
         fk, wk = med(fe[kern]["FETCH_SIZE"]), med(wr[kern]["WRITE_SIZE"])
         e = {"kernel": kern, "shape": [m, n, k], "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
@@ -34,4 +34,8 @@ while args:
              "TCC_HIT": med(wr[kern].get("TCC_HIT_sum", [0])), "TCC_MISS": med(wr[kern].get("TCC_MISS_sum", [0])),
              "dispatches": len(fe[kern]["FETCH_SIZE"]), "source": os.path.basename(d.rstrip("/"))}
         entries.append(e)
-print(json.dumps({"note": __doc__.split("\n", 1)[1].strip(), "entries": entries}, indent=1))
+# the hash scratch/prof.sh recorded ON THE BOX beside the measurements (bench.source_hash() of the profiled tree): a measurement
+# is only valid for the sources it was taken on (bench.committed_traffic compares it with the tree being benched)
+hashes = {open(os.path.join(d, "source_hash.txt")).read().strip() for d in sys.argv[1::4]}
+assert len(hashes) == 1, f"profile directories of different source trees: {hashes}"
+print(json.dumps({"note": __doc__.split("\n", 1)[1].strip(), "source_hash": hashes.pop(), "entries": entries}, indent=1))

@@ -266,6 +266,8 @@ def test_fused_tv_wave_hand_over_equals_the_recomputation(monkeypatch, m, n, fp3
         tau = float(np.sqrt(0.99 / est ** 2))
         res = eng.solve(1.0, tau, tau, 60, 1e-2)
         out = (eng.primal(), eng.dual()) + tuple(eng.history()) + (res.iterations,)
+        assert (", 8, false>" in eng.dominant_kernel()) == (waves == "8")
+        assert eng.handover_fallbacks() == 0          # no wave ever gave up on the LDS hand-over (cp_handover_fallbacks)
         eng.close()
         return out
 
@@ -276,3 +278,43 @@ def test_fused_tv_wave_hand_over_equals_the_recomputation(monkeypatch, m, n, fp3
         assert np.linalg.norm(u - v) <= tol * np.linalg.norm(v)
     for u, v in zip(a[2:4], b[2:4]):
         np.testing.assert_allclose(u, v, rtol=1e3 * tol, atol=10 * tol)
+
+
+@pytest.mark.parametrize("m,n,k,reg,bc", [(512, 24, 16, "tv", "neumann"), (576, 19, 11, "tv", "neumann"),
+                                           (512, 24, 16, "curvature", "dirichlet"), (520, 19, 7, "curvature", "neumann")])
+def test_forced_8wave_kernels_against_c_restatement(monkeypatch, m, n, k, reg, bc):
+    """The 8-wave instantiations (k_mf_fused_tv with the LDS hand-over, k_mf_fused_curv with 8 columns per workgroup), forced
+    at a size with 8-9 segments per column, directly against the C restatement over 120 iterations (they
+    were only compared with the 4-wave kernels): K = 16 and a K < 16 instantiation, ragged last segment, a column group that
+    ends inside a workgroup; the hand-over never falls back."""
+    from ma_amd import engine as E
+    from oracle import c_oracle
+    monkeypatch.setenv("CP_TUNE_FUSED_WAVES", "8")
+    monkeypatch.setenv("CP_TUNE_CURV_WAVES", "8")
+    imgs, u0, omega, h, A, b, T_u, gs = _setup(m, n, k, reg, bc)
+    mu = 0.2 if reg == "tv" else 20.0
+    nu = 1.2 * k
+    tau = sigma = 0.3 if reg == "tv" else 0.12
+    kmn = k * m * n
+    x0 = np.concatenate([u0.reshape(-1), 0.5 * T_u.reshape(-1, order="F")])
+    y0 = np.zeros((6 if reg == "tv" else 4) * kmn)
+    g = np.concatenate([gs[i].reshape(-1, order="F") for i in range(k)])
+    iters = 120
+    solve = c_oracle.nntv_chambolle_pock if reg == "tv" else c_oracle.nncurv_chambolle_pock
+    xr, yr, phr, dhr = solve(m, n, k, bc, h, mu, nu, 1.0, tau, sigma, iters, None, g, b, x0, y0)
+    eng = E.Engine(E.MODEL_MF_NN_TV if reg == "tv" else E.MODEL_MF_NN_CURV, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu)
+    name = eng.dominant_kernel()
+    assert name.startswith("k_mf_fused_tv<double, false") and name.endswith(", 1, 8, false>") if reg == "tv" else name.endswith(", 8>")
+    eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+    eng.set_primal(x0)
+    eng.linearize()
+    eng.set_nu(nu)
+    eng.solve(1.0, tau, sigma, iters, 0.0)
+    x, y = eng.primal(), eng.dual()
+    ph, dh = eng.history()
+    assert eng.handover_fallbacks() == 0
+    eng.close()
+    assert ph.shape == phr.shape == (iters + 1, 7)
+    np.testing.assert_allclose(ph[:, 0], phr[:, 0], rtol=1e-10)
+    np.testing.assert_allclose(dh[:, 0], dhr[:, 0], rtol=1e-10)
+    assert _rel(x, xr) < TOL and _rel(y, yr) < TOL

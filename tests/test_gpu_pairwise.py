@@ -34,25 +34,36 @@ def test_tv_registration_script(data_term, lam, tau, m, n):
     # is below it). tests/test_gpu_golden.py::test_pairwise_free_running_script_fixture does the same on the
     # reference's own Data/*.png with the stored envelope; per-step parity at 1e-10 is test_tv_registration_steps.
     Tn = od.normalize(T)
-    env_u, env_e = 0.0, np.zeros(steps)
+    env_u, env_v, env_e, env_d = 0.0, 0.0, np.zeros(steps), np.zeros(steps)
     for Tp in (np.nextafter(Tn, 2.0), np.nextafter(Tn, -1.0)):
-        up, _, hp, _ = od.tv_registration(R, Tp, lam, tau, iters, steps, data_term, keep_histories=True)   # normalize() leaves [0, 1] images alone up to rounding
+        up, vp, hp, _ = od.tv_registration(R, Tp, lam, tau, iters, steps, data_term, keep_histories=True)   # normalize() leaves [0, 1] images alone up to rounding
         env_u = max(env_u, _rel(up, ur))
+        env_v = max(env_v, _rel(vp, vr))
         for s in range(steps):
             if hp[s][0].shape == hr[s][0].shape:
                 env_e[s] = max(env_e[s], np.abs(hp[s][0][:, 0] - hr[s][0][:, 0]).max() / np.abs(hr[s][0][:, 0]).max())
+                env_d[s] = max(env_d[s], np.abs(hp[s][1][:, 0] - hr[s][1][:, 0]).max() / np.abs(hr[s][1][:, 0]).max())
             else:
-                env_e[s] = np.inf
-    tol_u = max(TOL, 2.0 * env_u)
-    for s, ((pg, dg), (pr, dr)) in enumerate(zip(hg, hr)):
-        tol_s = max(1e-9, 2.0 * env_e[:s + 1].max())
-        if np.isfinite(tol_s):
-            assert pg.shape == pr.shape and dg.shape == dr.shape      # identical iteration counts
-            np.testing.assert_allclose(pg[:, 0], pr[:, 0], rtol=0, atol=tol_s * np.abs(pr[:, 0]).max())
-    print(data_term, "u", _rel(u, ur), "v", _rel(v, vr), "envelope", env_u, env_e.max())
-    assert _rel(u, ur) < tol_u
-    if data_term == "SSD":
-        assert _rel(v, vr) < max(TOL, 2.0 * env_u)
+                env_e[s] = env_d[s] = np.inf     # the perturbed oracle stops at another iteration in this step
+    # steps before the first one whose iteration count the reference's own arithmetic does not pin
+    s_div = next((s for s in range(steps) if not np.isfinite(env_e[s])), steps)
+    for s, ((pg, dg), (pr, dr)) in enumerate(zip(hg[:s_div], hr[:s_div])):
+        assert pg.shape == pr.shape and dg.shape == dr.shape          # identical iteration counts
+        if data_term == "SSD":
+            # well conditioned: every column of both histories at 1e-9, as per-step parity (test_tv_registration_steps)
+            np.testing.assert_allclose(pg, pr, rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(dg, dr, rtol=1e-9, atol=1e-7)
+        else:
+            tol_p = max(1e-9, 2.0 * env_e[:s + 1].max())
+            tol_d = max(1e-9, 2.0 * env_d[:s + 1].max())
+            np.testing.assert_allclose(pg[:, 0], pr[:, 0], rtol=0, atol=tol_p * np.abs(pr[:, 0]).max())
+            np.testing.assert_allclose(dg[:, 0], dr[:, 0], rtol=0, atol=tol_d * np.abs(dr[:, 0]).max())
+    print(data_term, "u", _rel(u, ur), "v", _rel(v, vr), "envelope", env_u, env_v, env_e.max(), env_d.max())
+    if s_div < steps:
+        pytest.xfail(f"the oracle itself changes its iteration count at outer step {s_div} when T moves by one ulp: "
+                     f"steps 0..{s_div - 1} were compared, the rest is not pinned by the reference's arithmetic")
+    assert _rel(u, ur) < max(TOL, 2.0 * env_u)
+    assert _rel(v, vr) < max(TOL, 2.0 * env_v)
 
 
 @pytest.mark.parametrize("data_term,lam,tau", [("SAD", 4.0, 1.5), ("SSD", 50.0, 4.0)])
