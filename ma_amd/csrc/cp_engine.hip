@@ -78,6 +78,7 @@ struct cp_engine {
     double *g = nullptr, *b = nullptr, *Tu = nullptr, *img = nullptr, *imgR = nullptr;
     double *W[3] = {nullptr, nullptr, nullptr};   // W[2] = scratch
     double *xtmp = nullptr;
+    double *bnd[2] = {nullptr, nullptr};     // NN-TV: boundary arrays of P[0], P[1] (cp_mfnn_fused.cuh: bnd_block), in the storage type
     double *vlazy[2] = {nullptr, nullptr};   // variance-TV, k_var_lazy_tv: [abar | beta] per pixel, by iteration parity
     bool lazy_live = false;   // the y1 fields hold alpha (y1 = alpha - beta) until var_end
     double *part = nullptr, *part2 = nullptr;     // per-block partials (mf: one; pw: dual / primal)
@@ -249,7 +250,7 @@ extern "C" int cp_destroy(cp_handle h) {
     if (h->stage) hipFree(h->stage);
     if (h->vwarm) hipFree(h->vwarm);
     double *ptrs[] = {h->X[0], h->X[1], h->P[0], h->P[1], h->g, h->b, h->Tu, h->img, h->imgR, h->W[0], h->W[1],
-                      h->W[2], h->xtmp, h->vlazy[0], h->vlazy[1], h->part, h->part2, h->svout, h->hist_p, h->hist_d};
+                      h->W[2], h->xtmp, h->vlazy[0], h->vlazy[1], h->bnd[0], h->bnd[1], h->part, h->part2, h->svout, h->hist_p, h->hist_d};
     for (double *p : ptrs)
         if (p) hipFree(p);
     if (h->ctrl) hipFree(h->ctrl);
@@ -411,6 +412,11 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (mf) {
             for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
             HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
+            if (!var && h->reg == 0)
+                for (int a = 0; a < 2; ++a) {
+                    HIPCHK(hipMalloc(&h->bnd[a], sizeof(double) * bnd_elems(h->m, h->nl)));
+                    HIPCHK(hipMemsetAsync(h->bnd[a], 0, sizeof(double) * bnd_elems(h->m, h->nl), h->stream));
+                }
             if (h->var_fused)
                 for (int a = 0; a < 2; ++a) {
                     HIPCHK(hipMalloc(&h->vlazy[a], sizeof(double) * 2 * (size_t)h->fs));
@@ -954,8 +960,24 @@ static void launch_fused_t(cp_engine *h, const MfParams &P, const double *xp, do
         else if (h->K <= 12 && h->fused_ka) kern = k_mf_fused_tv<S, false, false, 12, false, 1, CP_WAVES, true>;
         else kern = k_mf_fused_tv<S, false, false, CP_KMAX, false, 1, CP_WAVES, true>;
     }
+    // boundary arrays travel with the dual buffers: read the one of y_n (pc), write the one of y_{n+1} (pn)
+    const S *bin = (const S *)h->bnd[pc == h->P[1] ? 1 : 0];
+    S *bout = (S *)h->bnd[pn == h->P[1] ? 1 : 0];
     hipLaunchKernelGGL(kern, dim3(h->nblk_tv), dim3(64 * h->fused_waves), 0, h->stream, P, (const S *)xp, (S *)xc, (const S *)pc,
-                       (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part);
+                       (S *)pn, (const S *)h->g, (const S *)h->b, W, (const CpCtrl *)h->ctrl, h->part, bin, bout);
+}
+// boundary array of dual buffer `pb` (0 / 1) for the storage columns [jc0, jc1) from the buffer's y2 fields: after a kernel
+// other than k_mf_fused_tv wrote them (k_mf_dual at start-up, a halo message)
+static void fill_bnd(cp_engine *h, int pb, int jc0, int jc1) {
+    if (!h->bnd[pb] || jc1 <= jc0) return;
+    const long long tot = (long long)((h->m + 63) / 64) * (jc1 - jc0) * CP_BND_BLOCK;
+    const int grid = (int)std::max<long long>(1, std::min<long long>((tot + CP_BLOCK - 1) / CP_BLOCK, 2048));
+    if (h->fp32)
+        hipLaunchKernelGGL((k_mf_fill_bnd<float>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->nl, h->K, h->fs, jc0, jc1,
+                           (const float *)h->P[pb], (float *)h->bnd[pb]);
+    else
+        hipLaunchKernelGGL((k_mf_fill_bnd<double>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->nl, h->K, h->fs, jc0, jc1,
+                           (const double *)h->P[pb], h->bnd[pb]);
 }
 static void launch_fused(cp_engine *h, const MfParams &P, const double *xp, double *xc, const double *pc, double *pn,
                          const double *W) {
@@ -993,6 +1015,7 @@ static void launch_curv_y2_t(cp_engine *h, const MfParams &P, const double *xc, 
 static int mf_fused_start(cp_engine *h, const MfParams &P, double tol) {
     CpCtrl *ctrl = (CpCtrl *)h->ctrl;
     launch_mf_dual<0>(h, P, h->X[0], h->X[1], h->P[0], h->P[1], h->W[0], 0, 1);
+    if (h->reg == 0) fill_bnd(h, 1, 1, h->nl + 1);   // y_1 was written by k_mf_dual: its boundary array for the first fused launch
     hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, -1, 1, 0, 0, 0, tol, 0, 1),
                        h->part, ctrl, h->W[1], h->hist_p, h->hist_d);
     HIPCHK(hipGetLastError());
@@ -1920,6 +1943,10 @@ static int mg_halo(cp_handle h, int buf, int sel, int col, int pack, double *lin
                            (float *)b, (float *)lin);
     else
         hipLaunchKernelGGL((k_halo_copy<double>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->fs, nsel, base, h->K, col, pack, b, lin);
+    // a halo column of y2 arrived in a state buffer of the NN-TV model: its block of the boundary array (the fused kernel
+    // evaluates the primal step at (i, nl) from it)
+    if (!pack && base == sel && (buf == CP_BUF_P0 || buf == CP_BUF_P1) && (sel == CP_SEL_P_Y12 || sel == CP_SEL_ALL || sel == CP_SEL_P_Y2))
+        fill_bnd(h, buf == CP_BUF_P1 ? 1 : 0, col, col + 1);
     HIPCHK(hipGetLastError());
     return CP_OK;
 }
@@ -1944,6 +1971,7 @@ static int mg_state(cp_handle h, int xbuf, int pbuf, int pack, double *a7, doubl
                            (float *)pb, (float *)a7, (float *)a2);
     else
         hipLaunchKernelGGL((k_halo_state<double>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, h->m, h->fs, h->K, h->nl, pack, xb, pb, a7, a2);
+    if (!pack && a7) fill_bnd(h, pbuf == CP_BUF_P1 ? 1 : 0, h->nl + 1, h->nl + 2);   // y2 of the right halo column arrived
     HIPCHK(hipGetLastError());
     return CP_OK;
 }
@@ -1986,6 +2014,7 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
     switch (stage) {
         case CP_STAGE_DUAL0:
             launch_mf_dual<0>(h, P, h->X[0], h->X[1], h->P[0], h->P[1], h->W[0], 0, 1);
+            if (h->reg == 0) fill_bnd(h, 1, 1, h->nl + 1);   // cf. mf_fused_start
             {
                 int nrows_l = 0;
                 const double *rows_l = staged_partials(h, h->nblk, &nrows_l);

@@ -30,13 +30,13 @@ struct PrimalAt { double ux, uy, uxo, uyo, wx, wy, y1, gx, gy, v0, v1, v2, v3; }
 // what one evaluation loads: y1, grad T, the four y2 components at the position and at their adjoint neighbours, u_{n-1}
 template <typename S>
 struct ImgLoads { S y1, gx, gy, v0, v1, v2, v3, w0m, w1m, w2m, w3m, uxo, uyo, l0, l1, l2, l3; };   // as stored (see bld_raw)
-// Measured (round 3, profiles/r03_exp_reads.txt, r03_exp_handover.txt): dropping the (i-1, j) loads altogether saves 1.2 GB of
-// reads and 0.5 ms per launch of k_mf_fused_tv at 4096^2 x 16, but SHF = 1 -- lanes 1..63 from lane - 1, the first lane of the
-// segment still loads -- saves neither (8.59 vs 8.61 ms, FETCH_SIZE equal): the cost is the line under the segment, which that
-// one lane still fetches, not the element-shifted access. k_mf_fused_curv was 4 % slower with it. Off by default.
 #ifndef CP_FUSED_SHF
-#define CP_FUSED_SHF 0
+#define CP_FUSED_SHF 1
 #endif
+#define CP_BND_BLOCK 32     // values per (segment, column) block of the boundary array: [Dx u_x | Dx u_y][CP_KMAX images]
+// element index of the block of segment sg (row 64 sg - 1), storage column jc = j + 1 (0 and nl + 1: halo columns)
+__host__ __device__ inline size_t bnd_block(int sg, int jc, int nl) { return ((size_t)sg * (size_t)(nl + 2) + (size_t)jc) * CP_BND_BLOCK; }
+__host__ __device__ inline size_t bnd_elems(int m, int nl) { return bnd_block((m + 63) / 64 + 1, 0, nl); }
 // value of lane - 1 (lane 0 receives 0): one v_mov_b32 dpp wave_shr:1 per dword, no LDS traffic. Must be called where every
 // lane of the wave is active (a DPP read from a disabled lane delivers nothing): never inside one arm of a ?: on a
 // lane-dependent condition -- assign the result to a variable first. The empty volatile asm keeps the moves where the call
@@ -54,22 +54,36 @@ __device__ __forceinline__ S lane_shr1(S v) {
         return __builtin_bit_cast(float, r);
     }
 }
+// value of lane `src` (wave-uniform index) in every lane: v_readlane_b32 per dword
+template <typename S>
+__device__ __forceinline__ S lane_bcast(S v, int src) {
+    if constexpr (sizeof(S) == 8) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+    }
+}
 // SHF (round 3; lanes = consecutive rows, evaluated by every lane of the wave): the Dx components of y2 at (i-1, j) are the
-// values lane - 1 loaded for its own row, so they come from a cross-lane shift; only the first lane of the segment loads
-// its (i-1, j) -- the other lanes carry an offset beyond the descriptor's range and the range check drops them. The two
-// element-shifted wave-wide loads this replaces straddled five lines instead of four: 1.2 GB of reads and 0.5 ms per launch
-// at 4096^2 x 16 (profiles/r03_exp_reads.txt).
+// values lane - 1 loaded for its own row, so they come from a cross-lane shift; what is left is the row under the
+// segment, which only the segment's first lane needs. The two element-shifted wave-wide loads this replaces straddled five
+// lines instead of four: 1.2 GB of reads and 0.5 ms per launch at 4096^2 x 16 (profiles/r03_exp_reads.txt) -- and a load in
+// the first lane alone still fetches that fifth line (profiles/r03_exp_handover.txt: no gain). So that row comes from a
+// BOUNDARY ARRAY instead: for every segment sg and column j one block of 32 values [Dx u_x | Dx u_y][image] of row
+// 64 sg - 1, written by the launch that produces y (its lane 63 holds exactly these numbers) and read with ONE 256-byte
+// load per wave and step (bnd_block_*): 16 times fewer bytes than the 32 lines of the one-lane loads.
+// img_load<SHF>: w0m / w2m are not loaded, the caller passes the boundary values (uniform over the wave).
 template <typename S, bool LINEAR, bool SHF = false>
 __device__ __forceinline__ void img_load(const MfParams &P, int i, int jg, unsigned oc, unsigned fsb, const ImgRsrc &R,
-                                         ImgLoads<S> &q, int li = 0) {
+                                         ImgLoads<S> &q, S bnd0 = (S)0, S bnd2 = (S)0) {
     constexpr unsigned ES = (unsigned)sizeof(S);
     const int m = P.m;
     const unsigned oim = oc - ES, ojm = oc - ES * (unsigned)m;        // (i-1, j) and (i, j-1): inside the allocation (halo column)
     q.y1 = bld_raw<S>(R.y1, oc);
     q.gx = bld_raw<S>(R.g, oc); q.gy = bld_raw<S>(R.g, oc, fsb);
     q.v0 = bld_raw<S>(R.y2a, oc); q.v1 = bld_raw<S>(R.y2a, oc, fsb); q.v2 = bld_raw<S>(R.y2b, oc); q.v3 = bld_raw<S>(R.y2b, oc, fsb);
-    const unsigned oim_l = (!SHF || li == 0) ? oim : 0xFFFFFFFFu;
-    q.w0m = bld_raw<S>(R.y2a, oim_l); q.w2m = bld_raw<S>(R.y2b, oim_l);                  // Dx components: adjoint along i
+    if (SHF) { q.w0m = bnd0; q.w2m = bnd2; }                                             // first lane of the segment; others: lane - 1 (img_eval)
+    else { q.w0m = bld_raw<S>(R.y2a, oim); q.w2m = bld_raw<S>(R.y2b, oim); }             // Dx components: adjoint along i
     q.w1m = bld_raw<S>(R.y2a, ojm, fsb); q.w3m = bld_raw<S>(R.y2b, ojm, fsb);            // Dy components: adjoint along j
     q.uxo = bld_raw<S>(R.u, oc);
     q.uyo = bld_raw<S>(R.u, oc, fsb);
@@ -353,7 +367,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
                                                               const S *__restrict__ pin, S *__restrict__ pout,
                                                               const S *__restrict__ g, const S *__restrict__ b,
                                                               const double *__restrict__ W,
-                                                              const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
+                                                              const CpCtrl *__restrict__ ctrl, double *__restrict__ part,
+                                                              const S *__restrict__ bin, S *__restrict__ bout) {
     __shared__ double tiles[NWV * 2 * 16 * CP_TS];
     __shared__ double Wl[CP_KMAX * CP_KMAX];
     constexpr int R = 64 / CW;
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
     // without it 9.20-9.26 ms and 57.3 GB (37.9 GB read: neighbouring waves miss the same line at the same moment and both
     // fetch it); 4 waves with it 9.31-9.63 ms, 51.8 GB; 8 waves without it 10.2-10.6 ms
     constexpr bool HS = (CP_FUSED_HS != 0) && !LINEAR && CW == 1 && NWV == 8;
-    constexpr bool SHF = (CP_FUSED_SHF != 0) && CW == 1;   // (i-1, j) from lane - 1 (img_load)
+    constexpr bool SHF = (CP_FUSED_SHF != 0) && CW == 1;   // (i-1, j) from lane - 1 and the boundary array (img_load)
     __shared__ double xch_all[HS ? (NWV - 1) * 256 : 1];   // hand-over slots, one per pair of neighbouring waves
     __shared__ int hs_flags[3 * NWV];                       // pub[wave], ack[wave], broken[wave]
     const int stopped = ctrl->stop;
@@ -372,6 +387,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *tileA = tiles + wave * 2 * 16 * CP_TS, *tileB = tileA + 16 * CP_TS;
     double *carry = carry_all + wave * CP_KMAX * CW * 4;
+    const cp_rsrc Rbin = mk_rsrc(bin), Rbout = mk_rsrc(bout);
+    const bool bnd_on = lane < CP_BND_BLOCK;                                // the lanes that hold one value of a block
+    const unsigned bnd_lane = (unsigned)sizeof(S) * (unsigned)(lane & (CP_BND_BLOCK - 1));
+    // KS: a wave stores the boundary values of its own images only
+    const bool bnd_mine = !KS || (((lane & (CP_KMAX - 1)) & (NWV - 1)) == wave);
     const int li = lane & (R - 1), lc = lane / R;
     const int K = P.K, m = P.m;
     const size_t fs = (size_t)P.fs;
@@ -431,9 +451,23 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
             const unsigned off = ES * (unsigned)((j + 1) * m + i);
             const bool last_i = (i == m - 1);
 
+            // boundary blocks of this segment: row 64 sg - 1 of the own column and (waves that evaluate (i, j +- 1) from
+            // memory) of the neighbour column, requested before phase 1 so that they have arrived when the per-image loop starts; bacc collects lane 63's new Dx values, image by image, for the segment above
+            S bq0 = (S)0, bqj = (S)0, bacc = (S)0;
+#ifndef CP_BND_LATE
+#define CP_BND_LATE 0
+#endif
+            if (SHF && !CP_BND_LATE) {
+                bq0 = bld_raw<S>(Rbin, bnd_on ? (unsigned)(bnd_block(sg, j + 1, P.nl) * sizeof(S)) + bnd_lane : 0xFFFFFFFFu);
+                if (!hs_c) bqj = bld_raw<S>(Rbin, bnd_on ? (unsigned)(bnd_block(sg, j + 1 + oj, P.nl) * sizeof(S)) + bnd_lane : 0xFFFFFFFFu);
+            }
             // ---- phase 1: everything that couples the K images of this pixel ------------------------------------------
             fused_phase1<S, FULLK, KA>(P, K, valid, off, lane, fs, y3in, pin, Lin, y3out, Lout, Wl, tileA, tileB, sigma, tau,
                                        theta, maxs[PM_VL - CP_NSUM], acc1, acc2);
+            if (SHF && CP_BND_LATE) {
+                bq0 = bld_raw<S>(Rbin, bnd_on ? (unsigned)(bnd_block(sg, j + 1, P.nl) * sizeof(S)) + bnd_lane : 0xFFFFFFFFu);
+                if (!hs_c) bqj = bld_raw<S>(Rbin, bnd_on ? (unsigned)(bnd_block(sg, j + 1 + oj, P.nl) * sizeof(S)) + bnd_lane : 0xFFFFFFFFu);
+            }
 
             // ---- phase 2: per image: primal step at the own pixel and at (i, j+1); (i +- 1, j) from a neighbour lane ------
             // where the i-neighbour's own-pixel result comes from: lane +- 1 of this step; for lane 63 the hand-over of the
@@ -458,14 +492,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
                 const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
                 PrimalAt r0, rj;
                 ImgLoads<S> q0, qj;
-                img_load<S, LINEAR, SHF>(P, i, jg, off, fsb, R, q0, li);
+                img_load<S, LINEAR, SHF>(P, i, jg, off, fsb, R, q0, lane_bcast<S>(bq0, k), lane_bcast<S>(bq0, CP_KMAX + k));
                 // (i, j+1): the wave of the next column computes exactly this as its own-pixel result and hands it over through
                 // LDS (hs_take below); only a wave without such a neighbour -- the last of the workgroup, the last column of a
                 // slab -- loads and evaluates the position itself. Evaluated by every lane (no lane-dependent branch).
 #ifdef CP_EXP   // 4: no (i, j+1) evaluation from memory at all
                 if (CP_EXP & 4) qj = q0; else
 #endif
-                if (!hs_c) img_load<S, LINEAR, SHF>(P, i, jg + oj, offj, fsb, R, qj, li);
+                if (!hs_c) img_load<S, LINEAR, SHF>(P, i, jg + oj, offj, fsb, R, qj, lane_bcast<S>(bqj, k), lane_bcast<S>(bqj, CP_KMAX + k));
                 const S bb_raw = bld_raw_stream<S>(mk_rsrc(b + (size_t)k * fs), off);
                 // fp32 storage: keep the float -> double conversions behind the whole group of loads (left alone, the compiler
                 // converts each value as it arrives into the register the next load is waiting for: one load in flight)
@@ -477,8 +511,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
                     if (hs_c) {
                         if (!hs_take(xr, fl + (wave + 1), fl + NWV + wave, fl + 2 * NWV + (wave + 1), ++cseq, lane, rj.ux, rj.uy, rj.uxo, rj.uyo)) {
                             ++hs_fb;
-                            img_load<S, LINEAR, SHF>(P, i, jg + oj, offj, fsb, R, qj, li);      // never in practice: see hs_take
-                            img_eval<S, LINEAR, SHF>(P, i, jg + oj, qj, cnx, cny, rj, li);
+                            img_load<S, LINEAR, false>(P, i, jg + oj, offj, fsb, R, qj);         // never in practice: see hs_take
+                            img_eval<S, LINEAR, false>(P, i, jg + oj, qj, cnx, cny, rj);
                         }
                     } else {
                         img_eval<S, LINEAR, SHF>(P, i, jg + oj, qj, cnx, cny, rj, li);
@@ -557,11 +591,17 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
                 if (sizeof(S) == 4) { n0 = rnd<S>(n0); n1 = rnd<S>(n1); n2 = rnd<S>(n2); n3 = rnd<S>(n3); }
                 bst<S>(Ro1, off_st, 0u, y1n);
                 bst<S>(Ro2a, off_st, 0u, n0); bst<S>(Ro2a, off_st, fsb, n1); bst<S>(Ro2b, off_st, 0u, n2); bst<S>(Ro2b, off_st, fsb, n3);
+                if (SHF) {   // row 64 sg + 63 = the row under segment sg + 1: lane k keeps Dx u_x of image k, lane 16 + k Dx u_y
+                    const S t0 = lane_bcast<S>((S)n0, 63), t2 = lane_bcast<S>((S)n2, 63);
+                    bacc = (lane == k) ? t0 : ((lane == CP_KMAX + k) ? t2 : bacc);
+                }
                 maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], valid ? fabs(y1n) : 0.0);
                 maxs[DM_S1 - CP_NSUM] = fmax(maxs[DM_S1 - CP_NSUM], valid ? s1v : 0.0);
                 sums[DS_UX] += vmask * ux;
                 sums[DS_UY] += vmask * uy;
             }
+            if (SHF)   // one 256-byte store per wave and step (lanes of a column past the slab / of another wave's images: dropped)
+                bst<S>(Rbout, (colv && bnd_mine && bnd_on) ? (unsigned)(bnd_block(sg + 1, j + 1, P.nl) * sizeof(S)) + bnd_lane : 0xFFFFFFFFu, 0u, (double)bacc);
             wave_lds_sync();   // hand-over and tiles of this step are complete before the next step touches them
         }
     }
@@ -600,6 +640,24 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
             }
             out[e] = v;
         }
+    }
+}
+
+// Boundary array of a dual buffer that some other kernel wrote (k_mf_dual at start-up, a halo message): block (sg, jc) <-
+// the Dx components of y2 at row 64 sg - 1, storage columns jc0 <= jc < jc1 (0 and nl + 1 are the halo columns).
+template <typename S>
+__global__ __launch_bounds__(CP_BLOCK) void k_mf_fill_bnd(int m, int nl, int K, int fs, int jc0, int jc1, const S *__restrict__ p,
+                                                          S *__restrict__ bnd) {
+    const int nseg = (m + 63) / 64, ncol = jc1 - jc0;
+    const long long tot = (long long)nseg * ncol * CP_BND_BLOCK;
+    for (long long gid = (long long)blockIdx.x * CP_BLOCK + threadIdx.x; gid < tot; gid += (long long)gridDim.x * CP_BLOCK) {
+        const int e = (int)(gid % CP_BND_BLOCK);
+        const long long r = gid / CP_BND_BLOCK;
+        const int jc = jc0 + (int)(r % ncol), sg = 1 + (int)(r / ncol);     // sg = 1 .. nseg
+        const int c = e / CP_KMAX, k = e % CP_KMAX, row = 64 * sg - 1;
+        S v = (S)0;
+        if (k < K && row < m) v = p[((size_t)K + 4 * (size_t)k + 2 * (size_t)c) * fs + (size_t)jc * m + row];
+        bnd[bnd_block(sg, jc, nl) + e] = v;
     }
 }
 
