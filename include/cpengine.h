@@ -82,7 +82,9 @@ enum cp_flag { CP_FLAG_VAR_SSD_SWAP = 1,
 typedef struct cp_problem_desc {
     int32_t model;      /* CP_MODEL_*                                                        */
     int32_t m, n;       /* image rows, columns (column-major, rows contiguous)               */
-    int32_t k;          /* number of images: mf_nn models 1..16, variance models 1..64; 1 for pairwise */
+    int32_t k;          /* number of images: mf_nn models 1..32 (the reference has no limit: NNE/nuclear_norm_constraint.m:34-37;
+                         * 1..16 run the fused kernels, 17..32 the general path -- one GPU, fp64 storage), variance models
+                         * 1..64; 1 for pairwise */
     int32_t bc;         /* CP_BC_* ; pairwise models always use neumann (script form)        */
     int32_t device;     /* HIP device ordinal                                                */
     int32_t batch;      /* number of independent problems of this shape in the handle (>=1)  */

@@ -6,6 +6,7 @@
 #define CP_BLOCK 256          // threads per workgroup (4 waves)
 #define CP_WAVES (CP_BLOCK / 64)
 #define CP_KMAX 16            // max images per mf_nn problem (one 16x16 f64 MFMA tile)
+#define CP_KBIG 32            // max images of the mf_nn models on the general path (K > 16: 2 x 2 MFMA tiles, cp_mfnn_big.cuh)
 #define CP_VAR_KMAX 64        // max images of the variance models (no K x K spectral work: only the LDS hand-over row scales with K)
 #define CP_TS 66              // LDS tile row stride (doubles): conflict-free ds_read_b64 in MFMA order
 #define CP_NSUM 12            // per-pass partial sums   (slots 0..11)
@@ -71,6 +72,56 @@ __device__ __forceinline__ void gram_tile_accum(const double *tile, double4_t &a
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
     }
 }
+
+// The same for KM = 16 * NT images (K > 16: NT = 2): tile [KM][CP_TS], NT x NT accumulators,
+// acc.a[a * NT + b][r] = G[16 a + (lane>>4) + 4r][16 b + (lane&15)].
+template <int NT>
+struct GramAcc { double4_t a[NT * NT]; };
+template <int NT>
+__device__ __forceinline__ void gram_acc_zero(GramAcc<NT> &acc) {
+#pragma unroll
+    for (int q = 0; q < NT * NT; ++q) acc.a[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+}
+template <int NT>
+__device__ __forceinline__ void gram_tile_accum_n(const double *tile, GramAcc<NT> &acc) {
+    const int lane = threadIdx.x & 63;
+    const double *src = tile + (lane & 15) * CP_TS + (lane >> 4);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        double v[NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) v[a] = src[a * 16 * CP_TS + 4 * t];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc.a[a * NT + b] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[a], v[b], acc.a[a * NT + b], 0, 0, 0);
+    }
+}
+// fixed-order sum over the waves, (16 NT)^2 entries row-major to out[]; stage: LDS scratch of NWV * (16 NT)^2 doubles
+template <int NT, int NWV = CP_WAVES>
+__device__ __forceinline__ void gram_block_store_n(const GramAcc<NT> &acc, double *stage, double *out) {
+    constexpr int KM = 16 * NT, E = KM * KM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * a + (lane >> 4) + 4 * r, col = 16 * b + (lane & 15);
+                stage[wave * E + row * KM + col] = acc.a[a * NT + b][r];
+            }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += NWV * 64) {
+        double v = stage[e];
+        for (int w = 1; w < NWV; ++w) v += stage[w * E + e];
+        out[e] = v;
+    }
+    __syncthreads();
+}
+// doubles per row of the partial buffer for kernels built for up to KM images: scalars + 2 Gram matrices
+template <int KM>
+__host__ __device__ constexpr int cp_pstride() { return CP_NSCAL + 2 * KM * KM; }
 
 // Sum the 4 waves' Gram accumulators in fixed order and write the 256 entries to out[].
 // stage: LDS scratch of CP_WAVES*256 doubles.

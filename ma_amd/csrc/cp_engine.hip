@@ -11,6 +11,7 @@
 
 #include "../../include/cpengine.h"
 #include "cp_mfnn_fused.cuh"
+#include "cp_mfnn_big.cuh"
 #include "cp_mfnn_curv.cuh"
 #include "cp_var.cuh"
 #include "cp_var_fused.cuh"
@@ -72,6 +73,7 @@ struct cp_engine {
     int gt = 0;          // pairwise: GT_*
     int nc = 1;          // pairwise: components of u
     int m = 0, nl = 0, K = 1, npix = 0, fs = 0, batch = 1;
+    int km = CP_KMAX;    // extent the K x K kernels of this handle are built for: 16, or CP_KBIG (32) for mf_nn with K > 16 (cp_mfnn_big.cuh)
     int nxf = 0, npf = 0;   // fields per problem
     size_t xN = 0, pN = 0;  // doubles per x / p buffer (all problems)
     double *X[2] = {nullptr, nullptr}, *P[2] = {nullptr, nullptr};
@@ -274,8 +276,14 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
     if (mf) {
         // the nuclear-norm models do their K x K spectral work on one 16 x 16 MFMA tile / one-wave Jacobi; the variance models
         // have none and take up to CP_VAR_KMAX images (the reference's real data sets have k = size(data, 3) frames)
-        const int kmax = var ? CP_VAR_KMAX : CP_KMAX;
+        // nuclear-norm models: up to 16 images on one MFMA tile / one-wave Jacobi with the fused kernels; 17..32 on the general
+        // path (split passes built for 32 images, cp_mfnn_big.cuh) -- one GPU, fp64 storage
+        const int kmax = var ? CP_VAR_KMAX : CP_KBIG;
         if (d.k < 1 || d.k > kmax) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported k = %d (1..%d)", d.k, kmax);
+        if (!var && d.k > CP_KMAX && (d.flags & CP_FLAG_FP32))
+            CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported k = %d > %d images in fp32 storage (the general path is fp64)", d.k, CP_KMAX);
+        if (!var && d.k > CP_KMAX && d.n_global > 0 && d.n_global != d.n)
+            CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported row slabs with k = %d > %d images", d.k, CP_KMAX);
         if ((d.model == CP_MODEL_MF_NN_TV || d.model == CP_MODEL_VAR_TV) && d.bc != CP_BC_NEUMANN && d.bc != CP_BC_LINEAR)
             CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");   // finite_difference_operator.m:35
         if (d.bc < 0 || d.bc > 2) CP_FAIL(CP_ERR_BAD_BC, "cpengine:badBC Unknown boundary condition!");
@@ -313,6 +321,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
     h->batch = h->d.batch;
     if (mf) {
         h->K = d.k;
+        h->km = (!var && d.k > CP_KMAX) ? CP_KBIG : CP_KMAX;
         h->reg = (d.model == CP_MODEL_MF_NN_TV || d.model == CP_MODEL_VAR_TV) ? 0 : 1;
         if (var) {
             h->nxf = 2 * h->K;                               // x = u only, NNE/var_tv...:102
@@ -358,6 +367,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         HIPCHK(hipMalloc(&h->img, sizeof(double) * imgN));
         if (!mf && h->gt != GT_SAD_DEN) HIPCHK(hipMalloc(&h->imgR, sizeof(double) * imgN));
         h->nblk = grid_for(h);
+        if (h->km == CP_KBIG) h->nblk = std::min(h->nblk, 256);   // k_big_* reduce the partial rows without a first stage
         // k_mf_fused_tv: one workgroup task per (part of a column, group of 4 columns), up to 4096 workgroups (512 are
         // resident: 2 per CU), tasks strided by the grid; a multiple of 8 workgroups keeps a part on one XCD. Measured at
         // 4096^2 x 16: 10.4-10.7 ms for grids of 4096, 2048, 1024; 10.8 ms for 512 (persistent).
@@ -410,7 +420,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         }
         h->nblk_var = std::min(h->nblk_var, h->nblk_fused);
         if (mf) {
-            for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * 256));
+            for (int a = 0; a < 3; ++a) HIPCHK(hipMalloc(&h->W[a], sizeof(double) * h->km * h->km));
             HIPCHK(hipMalloc(&h->xtmp, sizeof(double) * h->xN));
             if (!var && h->reg == 0)
                 for (int a = 0; a < 2; ++a) {
@@ -422,18 +432,19 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
                     HIPCHK(hipMalloc(&h->vlazy[a], sizeof(double) * 2 * (size_t)h->fs));
                     HIPCHK(hipMemsetAsync(h->vlazy[a], 0, sizeof(double) * 2 * (size_t)h->fs, h->stream));
                 }
-            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(std::max(std::max(h->nblk, h->nblk_fused), h->nblk_tv), h->nblk_y2) * CP_PSTRIDE));
+            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(std::max(std::max(h->nblk, h->nblk_fused), h->nblk_tv), h->nblk_y2) *
+                                           (h->km == CP_KBIG ? cp_pstride<CP_KBIG>() : CP_PSTRIDE)));
             HIPCHK(hipMalloc(&h->part2, sizeof(double) * (size_t)(CP_FUSED_MAXGRID / CP_S1_GROUP) * CP_PSTRIDE));
-            HIPCHK(hipMalloc(&h->svout, sizeof(double) * (16 + 256 + 256)));
+            HIPCHK(hipMalloc(&h->svout, sizeof(double) * (h->km + 2 * h->km * h->km)));
             HIPCHK(hipMalloc(&h->red, sizeof(double) * CP_PSTRIDE));
             if (h->fp32) HIPCHK(hipMalloc(&h->stage, sizeof(double) * h->npix));
-            HIPCHK(hipMalloc(&h->vwarm, sizeof(double) * 512));
-            HIPCHK(hipMemsetAsync(h->vwarm, 0, sizeof(double) * 512, h->stream));
+            HIPCHK(hipMalloc(&h->vwarm, sizeof(double) * 2 * h->km * h->km));
+            HIPCHK(hipMemsetAsync(h->vwarm, 0, sizeof(double) * 2 * h->km * h->km, h->stream));
             HIPCHK(hipMalloc(&h->ctrl, sizeof(CpCtrl)));
             HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(CpCtrl), h->stream));
-            hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1]);
+            hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1], h->km);
             hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[2],
-                               h->svout + 16 + 256);
+                               h->svout + h->km + h->km * h->km, h->km);
         } else {
             if (h->fp32) HIPCHK(hipMalloc(&h->stage, sizeof(double) * h->npix));
             // marching kernel when it yields enough waves to fill the chip (8 per SIMD slot would be 8192); small problems stay
@@ -612,7 +623,9 @@ extern "C" int cp_set_nu(cp_handle h, double nu) {
 
 // ------------------------------------------------------------------------------------------------
 static void launch_gram_field(cp_engine *h, const MfParams &P, const double *field, const double *Vm) {
-    if (h->fp32)
+    if (h->km == CP_KBIG)
+        hipLaunchKernelGGL((k_mf_gram_field<double, CP_KBIG>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, field, Vm, h->part);
+    else if (h->fp32)
         hipLaunchKernelGGL((k_mf_gram_field<float>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, (const float *)field, Vm, h->part);
     else
         hipLaunchKernelGGL((k_mf_gram_field<double>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, field, Vm, h->part);
@@ -678,16 +691,21 @@ extern "C" int cp_singular_values(cp_handle h, int which, double *sv) {
         CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg which = %d", which);
     }
     MfParams P = mf_params(h, 1.0, 1.0, 1.0);
-    double *ident = h->svout + 16 + 256, *vout = h->svout + 16;
+    const int km = h->km;
+    double *ident = h->svout + km + km * km, *vout = h->svout + km;
+    auto sv_eig = [&](const double *Vin) {
+        if (km == CP_KBIG) hipLaunchKernelGGL(k_big_sv_eig, dim3(1), dim3(CP_BIG_THREADS), 0, h->stream, h->nblk, h->part, Vin, h->svout);
+        else hipLaunchKernelGGL(k_mf_sv_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, h->nblk, h->part, Vin, h->svout);
+    };
     launch_gram_field(h, P, field, ident);
-    hipLaunchKernelGGL(k_mf_sv_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, h->nblk, h->part, ident, h->svout);
+    sv_eig(ident);
     // second pass in the rotated basis; W[2] (scratch) receives the rotation
-    HIPCHK(hipMemcpyAsync(h->W[2], vout, sizeof(double) * 256, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->W[2], vout, sizeof(double) * km * km, hipMemcpyDeviceToDevice, h->stream));
     launch_gram_field(h, P, field, h->W[2]);
-    hipLaunchKernelGGL(k_mf_sv_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, h->nblk, h->part, h->W[2], h->svout);
+    sv_eig(h->W[2]);
     HIPCHK(hipGetLastError());
-    double lam[16];
-    HIPCHK(hipMemcpyAsync(lam, h->svout, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
+    double lam[CP_KBIG];
+    HIPCHK(hipMemcpyAsync(lam, h->svout, sizeof(double) * km, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> s(h->K);
     for (int i = 0; i < h->K; ++i) s[i] = std::sqrt(std::max(lam[i], 0.0));
@@ -799,6 +817,15 @@ extern "C" int cp_apply_At(cp_handle h, const double *y, double *x) { return app
 template <int MODE>
 static void launch_mf_dual(cp_engine *h, const MfParams &P, const double *xc, const double *xo, const double *pin,
                            double *pout, const double *W, int cc, int co) {
+    if (h->km == CP_KBIG) {   // K > 16: the same kernel built for 32 images (fp64 storage only)
+        if (h->reg == 0)
+            hipLaunchKernelGGL((k_mf_dual<double, MODE, 0, CP_KBIG>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout,
+                               h->g, h->b, W, (const CpCtrl *)h->ctrl, cc, co, h->part);
+        else
+            hipLaunchKernelGGL((k_mf_dual<double, MODE, 1, CP_KBIG>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xo, pin, pout,
+                               h->g, h->b, W, (const CpCtrl *)h->ctrl, cc, co, h->part);
+        return;
+    }
     if (h->fp32) {
         const float *xcf = (const float *)xc, *xof = (const float *)xo, *pinf = (const float *)pin;
         const float *gf = (const float *)h->g, *bf = (const float *)h->b;
@@ -820,6 +847,15 @@ static void launch_mf_dual(cp_engine *h, const MfParams &P, const double *xc, co
 template <int MODE>
 static void launch_mf_primal(cp_engine *h, const MfParams &P, const double *xc, double *xn, const double *p,
                              const double *W, int cc) {
+    if (h->km == CP_KBIG) {
+        if (h->reg == 0)
+            hipLaunchKernelGGL((k_mf_primal<double, MODE, 0, CP_KBIG>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g, W,
+                               (const CpCtrl *)h->ctrl, cc, h->part);
+        else
+            hipLaunchKernelGGL((k_mf_primal<double, MODE, 1, CP_KBIG>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, xc, xn, p, h->g, W,
+                               (const CpCtrl *)h->ctrl, cc, h->part);
+        return;
+    }
     if (h->fp32) {
         const float *xcf = (const float *)xc, *pf = (const float *)p, *gf = (const float *)h->g;
         if (h->reg == 0)
@@ -843,7 +879,7 @@ static void launch_mf_primal(cp_engine *h, const MfParams &P, const double *xc, 
 static inline int efused_warm(int n) { return (n > 1 && (n & 127) != 1) ? 1 : 0; }
 // split passes: k_mf_eig keeps its basis in vwarm[0..255], k_mf_fin in vwarm[256..511]
 static inline EigArgs with_warm(EigArgs A, const cp_engine *h, int n, int slot) {
-    A.vwarm = h->vwarm + 256 * slot;
+    A.vwarm = h->vwarm + h->km * h->km * slot;
     A.warm = efused_warm(n);
     return A;
 }
@@ -896,7 +932,7 @@ __global__ __launch_bounds__(1024) void k_mf_reduce_stage1(int nrows, const doub
 // partial rows of the last field kernel as the single-workgroup kernels read them (after stage 1 if there are more than
 // 128: a single workgroup reads about 18 rows per microsecond)
 static const double *staged_partials(cp_engine *h, int nrows, int *rows, bool scalars_only = false) {
-    if (nrows <= 128) { *rows = nrows; return h->part; }
+    if (nrows <= 128 || h->km == CP_KBIG) { *rows = nrows; return h->part; }   // K > 16: rows of cp_pstride<32>, at most 256 of them
     const int r2 = (nrows + CP_S1_GROUP - 1) / CP_S1_GROUP;
     hipLaunchKernelGGL(k_mf_reduce_stage1, dim3(r2, scalars_only ? 1 : (CP_PSTRIDE + 255) / 256), dim3(1024), 0, h->stream, nrows, h->part,
                        h->part2);
@@ -905,6 +941,20 @@ static const double *staged_partials(cp_engine *h, int nrows, int *rows, bool sc
 }
 static const double *fused_partials(cp_engine *h, int *rows) {
     return staged_partials(h, (h->reg == 0 && !h->var) ? h->nblk_tv : ((h->reg == 1 && !h->var) ? h->nblk_curv : h->nblk_fused), rows);
+}
+
+// the single-workgroup kernels of the split passes for this handle's extent (16: cp_mfnn_small.cuh, 32: cp_mfnn_big.cuh)
+static void launch_eig(cp_engine *h, const EigArgs &A, const double *rows, double *Wout) {
+    if (h->km == CP_KBIG)
+        hipLaunchKernelGGL(k_big_eig, dim3(1), dim3(CP_BIG_THREADS), 0, h->stream, A, rows, (CpCtrl *)h->ctrl, Wout, h->hist_p, h->hist_d);
+    else
+        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, rows, (CpCtrl *)h->ctrl, Wout, h->hist_p, h->hist_d);
+}
+static void launch_fin(cp_engine *h, const EigArgs &A, const double *rows) {
+    if (h->km == CP_KBIG)
+        hipLaunchKernelGGL(k_big_fin, dim3(1), dim3(CP_BIG_THREADS), 0, h->stream, A, rows, (CpCtrl *)h->ctrl, h->hist_p, h->hist_d);
+    else
+        hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, A, rows, (CpCtrl *)h->ctrl, h->hist_p, h->hist_d);
 }
 
 // iterations n = n0+1 .. n0+count of PDO/chambolle_pock.m:156-179 (state parity follows n)
@@ -918,8 +968,7 @@ static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int
         CPCHK(timer_begin(h, T_EIG));
         EigArgs Ae = with_warm(eig_args(h, P, n - 1, n, check, 0, 0, tol), h, n, 0);
         const double *rows_e = staged_partials(h, h->nblk, &Ae.nblk);
-        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, Ae, rows_e, ctrl, h->W[nxt], h->hist_p,
-                           h->hist_d);
+        launch_eig(h, Ae, rows_e, h->W[nxt]);
         CPCHK(timer_end(h, T_EIG));
         CPCHK(timer_begin(h, T_PRIMAL));
         launch_mf_primal<0>(h, P, h->X[cur], h->X[nxt], h->P[nxt], h->W[nxt], cur);
@@ -927,7 +976,7 @@ static int mf_iterations(cp_engine *h, const MfParams &P, int n0, int count, int
         CPCHK(timer_begin(h, T_FIN));
         EigArgs Af = with_warm(eig_args(h, P, n, n, 0, 1, nxt, tol), h, n, 1);
         const double *rows_f = staged_partials(h, h->nblk, &Af.nblk);
-        hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, Af, rows_f, ctrl, h->hist_p, h->hist_d);
+        launch_fin(h, Af, rows_f);
         CPCHK(timer_end(h, T_FIN));
     }
     HIPCHK(hipGetLastError());
@@ -1058,14 +1107,21 @@ static int mf_fused_iterations(cp_engine *h, const MfParams &P, int n0, int coun
 
 static int mf_begin(cp_engine *h) {
     CpCtrl *ctrl = (CpCtrl *)h->ctrl;
-    hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, ctrl, h->W[0], h->W[1]);
+    hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, ctrl, h->W[0], h->W[1], h->km);
     HIPCHK(hipMemcpyAsync(h->X[1], h->X[0], sizeof(double) * h->xN, hipMemcpyDeviceToDevice, h->stream));   // x_old = x0
     return CP_OK;
 }
 
 static int mf_end(cp_engine *h, const MfParams &P, int iterations) {
     const int fb = iterations & 1;
-    if (h->fp32) {
+    if (h->km == CP_KBIG) {
+        if (h->reg == 0)
+            hipLaunchKernelGGL((k_mf_materialize<double, 0, CP_KBIG>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[fb], h->X[0],
+                               h->P[fb], h->P[0], h->W[fb], (const CpCtrl *)h->ctrl, fb);
+        else
+            hipLaunchKernelGGL((k_mf_materialize<double, 1, CP_KBIG>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[fb], h->X[0],
+                               h->P[fb], h->P[0], h->W[fb], (const CpCtrl *)h->ctrl, fb);
+    } else if (h->fp32) {
         const float *xs = (const float *)h->X[fb], *ps = (const float *)h->P[fb];
         float *xd = (float *)h->X[0], *pd = (float *)h->P[0];
         if (h->reg == 0)
@@ -1080,7 +1136,7 @@ static int mf_end(cp_engine *h, const MfParams &P, int iterations) {
     else
         hipLaunchKernelGGL((k_mf_materialize<double, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->X[fb], h->X[0],
                            h->P[fb], h->P[0], h->W[fb], (const CpCtrl *)h->ctrl, fb);
-    hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1]);
+    hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1], h->km);
     HIPCHK(hipGetLastError());
     return CP_OK;
 }
@@ -1229,7 +1285,7 @@ static int var_end(cp_engine *h, const MfParams &P, int iterations) {
     else
         hipLaunchKernelGGL(k_var_materialize<double>, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->npf, (const double *)h->X[fb],
                            h->X[0], (const double *)h->P[fb], h->P[0], (const CpCtrl *)h->ctrl, fb);
-    hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1]);
+    hipLaunchKernelGGL(k_mf_reset_ctrl, dim3(1), dim3(256), 0, h->stream, (CpCtrl *)h->ctrl, h->W[0], h->W[1], h->km);
     HIPCHK(hipGetLastError());
     return CP_OK;
 }
@@ -1293,15 +1349,13 @@ static int solve_mf(cp_engine *h, double theta, double tau, double sigma, int ma
     CPCHK(mf_begin(h));
     // row 0: primal_objective(x0), dual_objective(y0)          chambolle_pock.m:89-106
     launch_mf_dual<1>(h, P, h->X[0], h->X[1], h->P[0], nullptr, h->W[0], 0, 1);
-    hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, 0, 0, 0, 0, 0, tol, 1), h->part, ctrl,
-                       h->W[2], h->hist_p, h->hist_d);
+    launch_eig(h, eig_args(h, P, 0, 0, 0, 0, 0, tol, 1), h->part, h->W[2]);
     launch_mf_primal<1>(h, P, h->X[0], nullptr, h->P[0], h->W[0], 0);
-    hipLaunchKernelGGL(k_mf_fin, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, 0, 0, 0, 0, 0, tol), h->part, ctrl,
-                       h->hist_p, h->hist_d);
+    launch_fin(h, eig_args(h, P, 0, 0, 0, 0, 0, tol), h->part);
     HIPCHK(hipGetLastError());
     int done = 0, stopped = 0, stop_iter = -1;
     const int chunk = 32;
-    const bool fused = (h->reg == 0) || h->curv_fused;
+    const bool fused = ((h->reg == 0) || h->curv_fused) && h->km == CP_KMAX;   // K > 16: the split passes
     if (fused && maxIter > 0) CPCHK(mf_fused_start(h, P, tol));
     while (done < maxIter && !stopped) {
         const int cnt = std::min(chunk, maxIter - done);
@@ -1319,8 +1373,7 @@ static int solve_mf(cp_engine *h, double theta, double tau, double sigma, int ma
         // the reference breaks on i == maxIter before evaluating the rule (chambolle_pock.m:137).
         const int cur = maxIter & 1;
         launch_mf_dual<1>(h, P, h->X[cur], h->X[cur ^ 1], h->P[cur], nullptr, h->W[cur], cur, cur ^ 1);
-        hipLaunchKernelGGL(k_mf_eig, dim3(1), dim3(CP_RED_THREADS), 0, h->stream, eig_args(h, P, maxIter, -1, 0, 0, 0, tol),
-                           h->part, ctrl, h->W[2], h->hist_p, h->hist_d);
+        launch_eig(h, eig_args(h, P, maxIter, -1, 0, 0, 0, tol), h->part, h->W[2]);
         HIPCHK(hipGetLastError());
     }
     const int iterations = stopped ? stop_iter : maxIter;
@@ -1668,7 +1721,7 @@ extern "C" int cp_iterate_begin(cp_handle h, double theta, double tau, double si
     if (h->mf) {
         const MfParams P = mf_params(h, theta, tau, sigma);
         CPCHK(mf_begin(h));
-        if ((h->reg == 0 || h->curv_fused) && !h->var) CPCHK(mf_fused_start(h, P, 0.0));
+        if ((h->reg == 0 || h->curv_fused) && !h->var && h->km == CP_KMAX) CPCHK(mf_fused_start(h, P, 0.0));
         if (h->var && h->var_fused) CPCHK(var_fused_start(h, P));
     } else {
         HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(PwCtrl) * h->batch, h->stream));
@@ -1693,7 +1746,7 @@ extern "C" int cp_iterate_steps(cp_handle h, int32_t iters) {
         const MfParams P = mf_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
         if (h->var && h->var_fused) CPCHK(var_fused_iterations(h, P, h->it_n, iters, 0, 0.0));
         else if (h->var) CPCHK(var_iterations(h, P, h->it_n, iters, 0, 0.0));
-        else if (h->reg == 0 || h->curv_fused) CPCHK(mf_fused_iterations(h, P, h->it_n, iters, 0, 0.0));
+        else if ((h->reg == 0 || h->curv_fused) && h->km == CP_KMAX) CPCHK(mf_fused_iterations(h, P, h->it_n, iters, 0, 0.0));
         else CPCHK(mf_iterations(h, P, h->it_n, iters, 0, 0.0));
     } else {
         const PwParams P = pw_params(h, h->mg_theta, h->mg_tau, h->mg_sigma);
@@ -1780,7 +1833,9 @@ extern "C" int cp_dominant_kernel(cp_handle h, char *buf, int32_t len) {
     const char *tf[2] = {"false", "true"};
     char name[256];
     const int K = h->K;
-    if (h->mf && !h->var && h->reg == 0) {
+    if (h->mf && !h->var && h->km == CP_KBIG) {
+        snprintf(name, sizeof name, "k_mf_dual<double, 0, %d, 32>", h->reg);
+    } else if (h->mf && !h->var && h->reg == 0) {
         const bool lin = h->d.bc == CP_BC_LINEAR, n21 = (h->d.flags & CP_FLAG_MFNN_NORM21) != 0;
         int ka = CP_KMAX, cw = 1, nwv = CP_WAVES;
         bool fullk = false, ks = false;
@@ -1801,7 +1856,7 @@ extern "C" int cp_dominant_kernel(cp_handle h, char *buf, int32_t len) {
         const bool lin_eff = lin && nwv == CP_WAVES && cw == 1 && !ks;
         snprintf(name, sizeof name, "k_mf_fused_tv<%s, %s, %s, %d, %s, %d, %d, %s>", S, tf[lin_eff], tf[fullk], ka, tf[n21 && nwv == CP_WAVES && cw == 1 && !ks], cw, nwv, tf[ks]);
     } else if (h->mf && !h->var) {
-        if (!h->curv_fused) snprintf(name, sizeof name, "k_mf_dual<%s, 0, 1>", S);
+        if (!h->curv_fused) snprintf(name, sizeof name, "k_mf_dual<%s, 0, 1, 16>", S);
         else {
             const bool neu = h->d.bc == CP_BC_NEUMANN;
             int ka = CP_KMAX;
@@ -1984,6 +2039,7 @@ extern "C" int cp_mg_state_unpack(cp_handle h, int xbuf, int pbuf, const double 
 
 extern "C" int cp_mg_begin(cp_handle h, double theta, double tau, double sigma, int32_t max_iters) {
     if (!h || !h->mf || h->var) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_begin needs an mf_nn handle");
+    if (h->km != CP_KMAX) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported the staged (multi-GPU) iteration with k = %d > %d images", h->K, CP_KMAX);
     HIPCHK(hipSetDevice(h->d.device));
     CP_NOT_ITERATING(h);
     if (!h->linearized || !h->has_nu) CP_FAIL(CP_ERR_BAD_STATE, "cpengine:badState cp_mg_begin before linearize / set_nu");
@@ -2197,6 +2253,7 @@ extern "C" int cp_mg_stop_state(cp_handle h, int32_t *stopped, int32_t *stop_ite
 
 extern "C" int cp_mg_gram(cp_handle h, int which, const double *V, double *gram) {
     if (!h || !h->mf || h->var || !gram) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_mg_gram");
+    if (h->km != CP_KMAX) CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported cp_mg_gram with k = %d > %d images", h->K, CP_KMAX);
     HIPCHK(hipSetDevice(h->d.device));
     CP_NOT_ITERATING(h);
     const double *field = (which == 0) ? h->Tu

@@ -29,8 +29,8 @@ struct CpCtrl {
     double c[2][2];    // pending mean offsets of the two x buffers: true u = stored - c[buf][comp] (split passes)
     double cn[2];      // mean of the next un-projected u, known before the fused pass runs (see k_mf_fused_tv)
     double nu;         // radius of the nuclear-norm ball
-    double sv[CP_KMAX];      // last singular values computed by k_mf_eig (descending not guaranteed)
-    double svL[CP_KMAX];     // last singular values of B*L computed by k_mf_fin
+    double sv[CP_KBIG];      // last singular values computed by k_mf_eig (descending not guaranteed)
+    double svL[CP_KBIG];     // last singular values of B*L computed by k_mf_fin
 };
 
 struct MfParams {
@@ -55,52 +55,55 @@ enum { DM_Y1 = CP_NSUM, DM_S1,                                            // dua
 
 // y3 = y3~ * W for the wave's pixel: loads the K stored values, multiplies by the K x K matrix W (staged in LDS,
 // broadcast reads) and leaves the result in tile[k][lane]; returns sum_k y3[k].
-template <typename S>
+// KM: the extent the kernel is built for (16: one MFMA tile; 32 = CP_KBIG: the general path for K > 16, W is KM x KM)
+template <typename S, int KM = CP_KMAX>
 __device__ __forceinline__ double load_y3_apply_W(const S *__restrict__ y3base, int fs, int e, bool valid,
                                                   int K, const double *Wl, double *tile, int lane) {
-    double a[CP_KMAX];
+    double a[KM];
 #pragma unroll
-    for (int kp = 0; kp < CP_KMAX; ++kp) a[kp] = 0.0;
+    for (int kp = 0; kp < KM; ++kp) a[kp] = 0.0;
 #pragma unroll
-    for (int k = 0; k < CP_KMAX; ++k) {
+    for (int k = 0; k < KM; ++k) {
         if (k < K) {
             const double t = valid ? y3base[(size_t)k * fs + e] : 0.0;
 #pragma unroll
-            for (int kp = 0; kp < CP_KMAX; ++kp) a[kp] = fma(t, Wl[k * CP_KMAX + kp], a[kp]);
+            for (int kp = 0; kp < KM; ++kp) a[kp] = fma(t, Wl[k * KM + kp], a[kp]);
         }
     }
     double s = 0.0;
 #pragma unroll
-    for (int kp = 0; kp < CP_KMAX; ++kp) {
+    for (int kp = 0; kp < KM; ++kp) {
         tile[kp * CP_TS + lane] = a[kp];
         s += a[kp];
     }
     return s;
 }
 
-// stage the 16 x 16 matrix W (global) into LDS; the caller synchronises
+// stage the KM x KM matrix W (global) into LDS; the caller synchronises
+template <int KM = CP_KMAX>
 __device__ __forceinline__ void stage_W(const double *__restrict__ W, double *Wl) {
-    if (threadIdx.x < 256) Wl[threadIdx.x] = W[threadIdx.x];   // 256 entries
+    for (int e = threadIdx.x; e < KM * KM; e += blockDim.x) Wl[e] = W[e];
 }
 
 // MODE 0: update (writes pout); MODE 1: monitor only (y_new := y_in, nothing written but the partials).
 // REG 0: TV (forward differences + pointwise 2x2 nuclear norm); REG 1: curvature (Laplacian + SSD).
-template <typename S, int MODE, int REG>
+template <typename S, int MODE, int REG, int KM = CP_KMAX>
 __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const S *__restrict__ xc,
                                                       const S *__restrict__ xo,
                                                       const S *__restrict__ pin, S *__restrict__ pout,
                                                       const S *__restrict__ g, const S *__restrict__ b,
                                                       const double *__restrict__ W, const CpCtrl *__restrict__ ctrl,
                                                       int cbuf_c, int cbuf_o, double *__restrict__ part) {
-    __shared__ double tiles[CP_WAVES * 16 * CP_TS];
+    constexpr int NT = KM / 16;
+    __shared__ double tiles[CP_WAVES * KM * CP_TS];
     __shared__ double red[CP_WAVES * CP_NSCAL];
-    __shared__ double Wl[CP_KMAX * CP_KMAX];
+    __shared__ double Wl[KM * KM];
     if (ctrl->stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *tile = tiles + wave * 16 * CP_TS;
+    double *tile = tiles + wave * KM * CP_TS;
     const int K = P.K, m = P.m, fs = P.fs;
     const bool linear = (P.bc == 1), neumann = (P.bc == 0);
-    stage_W(W, Wl);
+    stage_W<KM>(W, Wl);
     __syncthreads();
     const double ccx = ctrl->c[cbuf_c][0], ccy = ctrl->c[cbuf_c][1];
     const double cox = ctrl->c[cbuf_o][0], coy = ctrl->c[cbuf_o][1];
@@ -114,7 +117,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const S *__res
     for (int a = 0; a < CP_NSUM; ++a) sums[a] = 0.0;
 #pragma unroll
     for (int a = 0; a < CP_NMAX; ++a) maxs[a] = 0.0;
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    GramAcc<NT> acc;
+    gram_acc_zero(acc);
 
     for (int base = blockIdx.x * CP_BLOCK; base < P.npix; base += gridDim.x * CP_BLOCK) {
         const int q = base + tid;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const S *__res
         const bool last_i = (i == m - 1), last_j = (jg == P.n_global - 1);
         const bool first_i = (i == 0), first_j = (jg == 0);
 
-        load_y3_apply_W(y3in, fs, e, valid, K, Wl, tile, lane);
+        load_y3_apply_W<S, KM>(y3in, fs, e, valid, K, Wl, tile, lane);
 
         double sumLbar = 0.0;
         for (int k = 0; k < K; ++k) {
@@ -289,29 +293,30 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_dual(MfParams P, const S *__res
             }
         }
         __syncthreads();
-        gram_tile_accum(tile, acc);
+        gram_tile_accum_n<NT>(tile, acc);
         __syncthreads();
     }
-    double *out = part + (size_t)blockIdx.x * CP_PSTRIDE;
+    double *out = part + (size_t)blockIdx.x * cp_pstride<KM>();
     block_reduce_store<CP_NSUM, CP_NMAX>(sums, maxs, red, out);
-    gram_block_store(acc, tiles, out + CP_NSCAL);
+    gram_block_store_n<NT>(acc, tiles, out + CP_NSCAL);
 }
 
-template <typename S, int MODE, int REG>
+template <typename S, int MODE, int REG, int KM = CP_KMAX>
 __global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const S *__restrict__ xc,
                                                         S *__restrict__ xn, const S *__restrict__ p,
                                                         const S *__restrict__ g, const double *__restrict__ W,
                                                         const CpCtrl *__restrict__ ctrl, int cbuf_c,
                                                         double *__restrict__ part) {
-    __shared__ double tiles[CP_WAVES * 16 * CP_TS];
+    constexpr int NT = KM / 16;
+    __shared__ double tiles[CP_WAVES * KM * CP_TS];
     __shared__ double red[CP_WAVES * CP_NSCAL];
-    __shared__ double Wl[CP_KMAX * CP_KMAX];
+    __shared__ double Wl[KM * KM];
     if (ctrl->stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *tile = tiles + wave * 16 * CP_TS;
+    double *tile = tiles + wave * KM * CP_TS;
     const int K = P.K, m = P.m, fs = P.fs;
     const bool linear = (P.bc == 1), neumann = (P.bc == 0);
-    stage_W(W, Wl);
+    stage_W<KM>(W, Wl);
     __syncthreads();
     const double ccx = ctrl->c[cbuf_c][0], ccy = ctrl->c[cbuf_c][1];
     const double tau = P.tau;
@@ -323,7 +328,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const S *__r
     for (int a = 0; a < CP_NSUM; ++a) sums[a] = 0.0;
 #pragma unroll
     for (int a = 0; a < CP_NMAX; ++a) maxs[a] = -1.0e300;
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    GramAcc<NT> acc;
+    gram_acc_zero(acc);
 
     for (int base = blockIdx.x * CP_BLOCK; base < P.npix; base += gridDim.x * CP_BLOCK) {
         const int q = base + tid;
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const S *__r
         const int e = q + m;
         const int jg = P.j_off + j;
 
-        const double s3 = load_y3_apply_W(y3, fs, e, valid, K, Wl, tile, lane);
+        const double s3 = load_y3_apply_W<S, KM>(y3, fs, e, valid, K, Wl, tile, lane);
         const double mean3 = s3 * P.invK;
         double sumL = 0.0;
         for (int k = 0; k < K; ++k) {
@@ -415,13 +421,13 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_primal(MfParams P, const S *__r
                 const double v = valid ? tile[k * CP_TS + lane] - mL : 0.0;
                 tile[k * CP_TS + lane] = v;
             }
-            for (int k = K; k < CP_KMAX; ++k) tile[k * CP_TS + lane] = 0.0;
+            for (int k = K; k < KM; ++k) tile[k * CP_TS + lane] = 0.0;
         }
         __syncthreads();
-        gram_tile_accum(tile, acc);
+        gram_tile_accum_n<NT>(tile, acc);
         __syncthreads();
     }
-    double *out = part + (size_t)blockIdx.x * CP_PSTRIDE;
+    double *out = part + (size_t)blockIdx.x * cp_pstride<KM>();
     block_reduce_store<CP_NSUM, CP_NMAX>(sums, maxs, red, out);
-    gram_block_store(acc, tiles, out + CP_NSCAL);
+    gram_block_store_n<NT>(acc, tiles, out + CP_NSCAL);
 }

@@ -517,17 +517,17 @@ __global__ __launch_bounds__(CP_RED_THREADS) void k_mf_fin(EigArgs A, const doub
 }
 
 // ---- state canonicalisation: apply pending offsets / W so that the stored vectors are the true ones ---
-template <typename S, int REG>
+template <typename S, int REG, int KM = CP_KMAX>
 __global__ __launch_bounds__(CP_BLOCK) void k_mf_materialize(MfParams P, const S *__restrict__ xs,
                                                              S *__restrict__ xd, const S *__restrict__ ps,
                                                              S *__restrict__ pd, const double *__restrict__ W,
                                                              const CpCtrl *__restrict__ ctrl, int cbuf) {
-    __shared__ double tiles[CP_WAVES * 16 * CP_TS];
-    __shared__ double Wl[CP_KMAX * CP_KMAX];
+    __shared__ double tiles[CP_WAVES * KM * CP_TS];
+    __shared__ double Wl[KM * KM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *tile = tiles + wave * 16 * CP_TS;
+    double *tile = tiles + wave * KM * CP_TS;
     const int K = P.K, fs = P.fs;
-    stage_W(W, Wl);
+    stage_W<KM>(W, Wl);
     __syncthreads();
     const double cx = ctrl->c[cbuf][0], cy = ctrl->c[cbuf][1];
     const int NY2 = (REG == 0) ? 4 : 2;
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_materialize(MfParams P, const S
         const int q = base + tid;
         const bool valid = q < P.npix;
         const int e = q + P.m;
-        load_y3_apply_W(ps + (size_t)(K + NY2 * K) * fs, fs, e, valid, K, Wl, tile, lane);
+        load_y3_apply_W<S, KM>(ps + (size_t)(K + NY2 * K) * fs, fs, e, valid, K, Wl, tile, lane);
         if (valid) {
             for (int k = 0; k < K; ++k) {
                 xd[(size_t)(2 * k) * fs + e] = (S)((double)xs[(size_t)(2 * k) * fs + e] - cx);
@@ -549,15 +549,18 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_materialize(MfParams P, const S
     }
 }
 
-__global__ void k_mf_reset_ctrl(CpCtrl *ctrl, double *W0, double *W1) {
+// km: extent of the W matrices (16, or CP_KBIG on the general path)
+__global__ void k_mf_reset_ctrl(CpCtrl *ctrl, double *W0, double *W1, int km = CP_KMAX) {
     const int t = threadIdx.x;
     if (t == 0) {
         ctrl->stop = 0; ctrl->stop_iter = -1;
         ctrl->c[0][0] = ctrl->c[0][1] = ctrl->c[1][0] = ctrl->c[1][1] = 0.0;
     }
-    const double v = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
-    W0[t] = v;
-    W1[t] = v;
+    for (int e = t; e < km * km; e += blockDim.x) {
+        const double v = ((e / km) == (e % km)) ? 1.0 : 0.0;
+        W0[e] = v;
+        W1[e] = v;
+    }
 }
 
 // ---- linearisation: T(u0), grad T(u0), b = T(u0) - grad T . u0   --------------------------------------
@@ -596,41 +599,43 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mf_warp(WarpParams P, const double
 }
 
 // ---- Gram of (B*field)*Vm for accurate singular values (nu_0, SV_history) -----------------------------
-template <typename S>
+template <typename S, int KM = CP_KMAX>
 __global__ __launch_bounds__(CP_BLOCK) void k_mf_gram_field(MfParams P, const S *__restrict__ field,
                                                             const double *__restrict__ Vm,
                                                             double *__restrict__ part) {
-    __shared__ double tiles[CP_WAVES * 16 * CP_TS];
+    constexpr int NT = KM / 16;
+    __shared__ double tiles[CP_WAVES * KM * CP_TS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *tile = tiles + wave * 16 * CP_TS;
+    double *tile = tiles + wave * KM * CP_TS;
     const int K = P.K, fs = P.fs;
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    GramAcc<NT> acc;
+    gram_acc_zero(acc);
     for (int base = blockIdx.x * CP_BLOCK; base < P.npix; base += gridDim.x * CP_BLOCK) {
         const int q = base + tid;
         const bool valid = q < P.npix;
         const int e = q + P.m;
-        double t3[CP_KMAX];
+        double t3[KM];
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < CP_KMAX; ++k) {
+        for (int k = 0; k < KM; ++k) {
             t3[k] = (valid && k < K) ? field[(size_t)k * fs + e] : 0.0;
             s += t3[k];
         }
         const double mean = s * P.invK;
 #pragma unroll
-        for (int k = 0; k < CP_KMAX; ++k) t3[k] = (valid && k < K) ? t3[k] - mean : 0.0;   // mean_free_operator.m:20
+        for (int k = 0; k < KM; ++k) t3[k] = (valid && k < K) ? t3[k] - mean : 0.0;   // mean_free_operator.m:20
 #pragma unroll
-        for (int kp = 0; kp < CP_KMAX; ++kp) {
+        for (int kp = 0; kp < KM; ++kp) {
             double a = 0.0;
 #pragma unroll
-            for (int k = 0; k < CP_KMAX; ++k) a = fma(t3[k], Vm[k * CP_KMAX + kp], a);
+            for (int k = 0; k < KM; ++k) a = fma(t3[k], Vm[k * KM + kp], a);
             tile[kp * CP_TS + lane] = a;
         }
         __syncthreads();
-        gram_tile_accum(tile, acc);
+        gram_tile_accum_n<NT>(tile, acc);
         __syncthreads();
     }
-    gram_block_store(acc, tiles, part + (size_t)blockIdx.x * CP_PSTRIDE + CP_NSCAL);
+    gram_block_store_n<NT>(acc, tiles, part + (size_t)blockIdx.x * cp_pstride<KM>() + CP_NSCAL);
 }
 
 // reduce + Jacobi; out[0..15] eigenvalues (diag), out[16..271] eigenvector matrix composed with Vin

@@ -46,6 +46,6 @@ def test_bad_arguments_are_reported_not_crashing():
     d.h[0] = d.h[1] = 1.0
     assert E.lib.cp_create(ctypes.byref(d), ctypes.byref(h)) != 0
     assert b"badArg" in E.lib.cp_last_error()
-    d.model, d.k = E.MODEL_MF_NN_TV, 17
+    d.model, d.k = E.MODEL_MF_NN_TV, 33      # mf_nn: up to 32 images (17..32 on the general path)
     assert E.lib.cp_create(ctypes.byref(d), ctypes.byref(h)) != 0
     assert b"unsupported" in E.lib.cp_last_error()

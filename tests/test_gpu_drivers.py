@@ -10,11 +10,12 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-@pytest.mark.parametrize("reg,bc,mu", [("tv", "neumann", 0.2), ("curvature", "dirichlet", 20.0)])
-def test_mf_nn_ml_driver(reg, bc, mu):
+@pytest.mark.parametrize("reg,bc,mu,k", [("tv", "neumann", 0.2, 4), ("curvature", "dirichlet", 20.0, 4),
+                                           ("tv", "neumann", 0.2, 18), ("curvature", "dirichlet", 20.0, 21)])   # K > 16: the general path
+def test_mf_nn_ml_driver(reg, bc, mu, k):
     from ma_amd import drivers as D, synth
     from oracle import drivers as od
-    m, n, k = 70, 66, 4           # two levels (35x33 -> 70x66), odd coarse size
+    m, n = 70, 66                 # two levels (35x33 -> 70x66), odd coarse size
     imgs = synth.dynamic_test_image(m, n, k).numpy()
     opt = dict(theta=1.0, maxIter=40, tol=1e-3, outerIter=[3, 2], mu=mu, nu_factor=[0.9, 0.9], bc=bc)
     keep_r, keep_g = {}, {}

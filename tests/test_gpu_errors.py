@@ -9,8 +9,13 @@ def test_create_errors():
     from ma_amd import engine as E
     with pytest.raises(E.CpEngineError, match="badBC"):          # NNE/finite_difference_operator.m:35
         E.Engine(E.MODEL_MF_NN_TV, 16, 16, k=3, bc="dirichlet")
+    E.Engine(E.MODEL_MF_NN_TV, 16, 16, k=17).close()            # mf_nn: 17..32 images on the general path (cp_mfnn_big.cuh)
     with pytest.raises(E.CpEngineError, match="unsupported"):
-        E.Engine(E.MODEL_MF_NN_TV, 16, 16, k=17)
+        E.Engine(E.MODEL_MF_NN_TV, 16, 16, k=33)
+    with pytest.raises(E.CpEngineError, match="unsupported"):    # ... in fp64 storage, on one GPU
+        E.Engine(E.MODEL_MF_NN_TV, 16, 16, k=17, flags=E.FLAG_FP32)
+    with pytest.raises(E.CpEngineError, match="unsupported"):
+        E.Engine(E.MODEL_MF_NN_CURV, 16, 8, k=20, bc="neumann", n_global=16, j_offset=0)
     E.Engine(E.MODEL_VAR_TV, 16, 16, k=64).close()              # variance models: up to 64 images
     with pytest.raises(E.CpEngineError, match="unsupported"):
         E.Engine(E.MODEL_VAR_TV, 16, 16, k=65)

@@ -318,3 +318,54 @@ def test_forced_8wave_kernels_against_c_restatement(monkeypatch, m, n, k, reg, b
     np.testing.assert_allclose(ph[:, 0], phr[:, 0], rtol=1e-10)
     np.testing.assert_allclose(dh[:, 0], dhr[:, 0], rtol=1e-10)
     assert _rel(x, xr) < TOL and _rel(y, yr) < TOL
+
+
+@pytest.mark.parametrize("reg,bc,m,n,k", [("tv", "neumann", 40, 36, 20), ("tv", "linear", 33, 19, 17), ("tv", "neumann", 70, 21, 32),
+                                          ("curvature", "dirichlet", 40, 36, 20), ("curvature", "neumann", 37, 50, 32)])
+def test_more_than_16_images_against_oracle(reg, bc, m, n, k):
+    """K > 16 (VERDICT r2 missing 1): the reference has no limit on the number of images (NNE/nuclear_norm_constraint.m:34-37,
+    the kidney demo's k = size(data, 3)). 17..32 images run on the general path -- split passes built for 32 images, 2 x 2
+    MFMA tiles per Gram matrix, 32 x 32 Jacobi (cp_mfnn_big.cuh) -- and must match the numpy oracle like every other size:
+    operators' singular values, power iteration, 60 iterations with warm-started eigensolves, histories, stop rule armed."""
+    from ma_amd import engine as E
+    from oracle import drivers as od
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    imgs, u0, omega, h, A, b, T_u, gs = _setup(m, n, k, reg, bc)
+    mu = 0.2 if reg == "tv" else 20.0
+    nu, tau = 1.5 * k, 0.3 if reg == "tv" else 0.12
+    kmn = k * m * n
+    ncomp = 6 if reg == "tv" else 4
+    rng = np.random.default_rng(11)
+    x0 = np.concatenate([u0.reshape(-1), 0.5 * T_u.reshape(-1, order="F")])
+    y0 = 0.01 * rng.standard_normal(ncomp * kmn)
+    Fh = lambda y, c, nargout: od.mf_nn_F(y, b, k, h, mu, nu, tau, c, nargout, reg)
+    Gh = lambda x, c, nargout: od.mf_nn_G(x, (m, n, k), c, nargout)
+    iters = 60
+    xr, yr, phr, dhr = cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, tau, iters, 1e-3)
+    eng = E.Engine(E.MODEL_MF_NN_TV if reg == "tv" else E.MODEL_MF_NN_CURV, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu)
+    assert eng.dominant_kernel() == f"k_mf_dual<double, 0, {0 if reg == 'tv' else 1}, 32>"
+    eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+    eng.set_primal(x0)
+    eng.linearize()
+    sv = eng.singular_values(0)                                  # nu_0 of the drivers: svd(B * T(u0)), NNE/mf_nn_tv...:173-175
+    Tc = T_u.reshape(m * n, k, order="F")
+    sv_ref = np.linalg.svd(Tc - Tc.mean(axis=1, keepdims=True), compute_uv=False)
+    np.testing.assert_allclose(sv[:k - 1], sv_ref[:k - 1], rtol=1e-10)
+    assert sv[k - 1] <= 1e-9 * sv[0]
+    est, n_power = eng.norm_estimate()
+    from oracle import operators as oo
+    e_ref = oo.matrix_norm(A, x0=od.normest_start(A.shape[1]))   # NNE/matrix_norm.m with the engine's deterministic start vector
+    assert n_power == len(e_ref) and abs(est - e_ref[-1]) <= 1e-11 * e_ref[-1]
+    eng.set_dual(y0)
+    eng.set_nu(nu)
+    res = eng.solve(1.0, tau, tau, iters, 1e-3)
+    x, y = eng.primal(), eng.dual()
+    ph, dh = eng.history()
+    eng.close()
+    assert ph.shape == phr.shape and dh.shape == dhr.shape and res.iterations == phr.shape[0] - 1
+    assert _rel(x, xr) < TOL
+    assert _rel(y, yr) < 1e-9
+    np.testing.assert_allclose(ph[:, :5], phr[:, :5], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(dh[:, :5], dhr[:, :5], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(ph[:, 5:], phr[:, 5:], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(dh[:, 5:], dhr[:, 5:], rtol=1e-6, atol=1e-8)
