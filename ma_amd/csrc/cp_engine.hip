@@ -299,11 +299,11 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         }
     }
     // the field kernels address a field with 32-bit byte offsets (ldo / sto, cp_device.cuh) and count pixels in int
-    if ((long long)d.m * ((long long)d.n + 2) * (long long)sizeof(double) >= (1LL << 32))
+    if (((long long)d.m * ((long long)d.n + 2) + 8192) * (long long)sizeof(double) >= (1LL << 32))   // + the field stagger (below)
         CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported a field of %d x %d doubles reaches 4 GiB (32-bit offsets inside a field)", d.m, d.n);
     // the buffer-addressed kernels of the multi-image models reach the second field of a pair through the descriptor's
     // uniform offset: lane offset + field size stays below 2^32 (whichever way the range check counts that offset)
-    if (mf && (long long)d.m * ((long long)d.n + 2) * (long long)sizeof(double) >= (1LL << 31))
+    if (mf && ((long long)d.m * ((long long)d.n + 2) + 8192) * (long long)sizeof(double) >= (1LL << 31))
         CP_FAIL(CP_ERR_UNSUPPORTED, "cpengine:unsupported a field of %d x %d doubles reaches 2 GiB (multi-image models)", d.m, d.n);
     cp_engine *h = new cp_engine();
     h->d = d;
@@ -318,6 +318,17 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
     h->mf = mf;
     h->var = var;
     h->m = d.m; h->nl = d.n; h->npix = d.m * d.n; h->fs = d.m * (d.n + 2);
+    // Field stagger (round 3, profiles/r03_field_pad.txt). m x (n + 2) doubles of the benchmark shapes are multiples of 64 KB, so
+    // every field of a buffer started at the same phase of the memory system's address interleave and the ~21 streams a wave
+    // reads and writes for one pixel met on the same channels: k_mf_fused_tv on a 4096 x 512 slab 1.25-1.30 ms, with fields
+    // staggered by 1-3 KB 1.07 (-15 %); 4096 x 1024 -7 %, 2048^2 -6 %, k_mf_fused_curv on the slab -16 %; multiples of 4 KB bring
+    // the loss back. Large multi-image fields are therefore padded so that the field stride is 3 KB modulo 64 KB (a multiple
+    // of 512 B: the 64-row segments of a wave stay aligned). At most 64 KB per field. CP_TUNE_FIELD_PAD=<elements> overrides.
+    if (mf && (long long)h->fs * (long long)sizeof(double) >= (256LL << 10)) {
+        const long long base = (long long)h->fs * (long long)sizeof(double), target = 3072, period = 65536;
+        h->fs += (int)((((target - base) % period + period) % period) / (long long)sizeof(double));
+    }
+    if (const char *ev = getenv("CP_TUNE_FIELD_PAD")) h->fs = d.m * (d.n + 2) + std::max(0, atoi(ev));
     h->batch = h->d.batch;
     if (mf) {
         h->K = d.k;
