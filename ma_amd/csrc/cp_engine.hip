@@ -73,6 +73,7 @@ struct cp_engine {
     int gt = 0;          // pairwise: GT_*
     int nc = 1;          // pairwise: components of u
     int m = 0, nl = 0, K = 1, npix = 0, fs = 0, batch = 1;
+    int parts8 = 0;      // CP_TUNE_PARTS8: parts per column of the 8-wave kernels (0: fused2_cap's rule)
     int km = CP_KMAX;    // extent the K x K kernels of this handle are built for: 16, or CP_KBIG (32) for mf_nn with K > 16 (cp_mfnn_big.cuh)
     int nxf = 0, npf = 0;   // fields per problem
     size_t xN = 0, pN = 0;  // doubles per x / p buffer (all problems)
@@ -127,6 +128,7 @@ static MfParams mf_params(const cp_engine *h, double theta, double tau, double s
     P.mu1 = h->d.h[0] * h->d.h[1];              // prod(h_grid), NNE/mf_nn_tv...:257
     P.mu2 = h->d.mu * (h->d.h[0] * h->d.h[1]);  // mu * prod(h_grid), :264
     P.norm21 = (h->d.flags & CP_FLAG_MFNN_NORM21) ? 1 : 0;
+    P.parts8 = h->parts8;
     if (P.norm21) { P.mu1 = 1.0; P.mu2 = h->d.mu; }   // SAD(y1, b, 1, ..), norm21(y2_j, mu, ..): NNE/mf_nn_tv_registration_no_ref.m:206,213
     P.sigma = sigma; P.tau = tau; P.theta = theta;
     P.ssd_swap = (h->d.flags & CP_FLAG_VAR_SSD_SWAP) ? 1 : 0;
@@ -396,13 +398,14 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             // hand-over is not amortised -- 2048^2 x 16: 2.58 vs 2.55 ms, 1024^2: 0.68 vs 0.66; 4096 x 512 (a slab): 1.37 vs 1.41
             // in favour of 8 waves. K = 5..15 (KA = 8, 12, 16 instantiations): 4096^2 x 12 7.39 vs 7.47 ms, x 8 4.83 vs 4.93
             h->fused_waves = CP_WAVES;
-        h->nblk_tv = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw, h->fused_waves) + 7) / 8 * 8, CP_FUSED_MAXGRID);
+        if (const char *ev = getenv("CP_TUNE_PARTS8")) h->parts8 = std::max(0, atoi(ev));
+        h->nblk_tv = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw, h->fused_waves, h->parts8) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         {
             h->var_waves = 8;
             bool force8v = false;
             if (const char *ev = getenv("CP_TUNE_VAR_WAVES")) { if (atoi(ev) == 4) h->var_waves = CP_WAVES; force8v = atoi(ev) == 8; }
             if (!(var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (!force8v && (fused2_tasks(h->m, h->nl, 1, 8) < 256 || fused2_geom(h->m, 64).steps < 8 || h->fp32))) h->var_waves = CP_WAVES;
-            h->nblk_var = (int)std::min<long long>((fused2_tasks(h->m, h->nl, 1, h->var_waves) + 7) / 8 * 8, CP_FUSED_MAXGRID);
+            h->nblk_var = (int)std::min<long long>((fused2_tasks(h->m, h->nl, 1, h->var_waves, h->parts8) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         }
         h->curv_fused = mf && !var && h->reg == 1;
         {

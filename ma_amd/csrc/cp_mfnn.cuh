@@ -39,6 +39,7 @@ struct MfParams {
     int bc;
     int fs;
     int ssd_swap;             // CP_FLAG_VAR_SSD_SWAP (variance models only)
+    int parts8;               // > 0: parts per column of the 8-wave kernels (CP_TUNE_PARTS8; 0: the rule of fused2_cap)
     int norm21;               // CP_FLAG_MFNN_NORM21: F2 = mu*||.||_{2,1} per image instead of the pointwise 2x2 nuclear norm
     double inv_h1, inv_h2;
     double mu1, mu2;          // h1*h2, mu*h1*h2

@@ -243,8 +243,9 @@ __host__ __device__ inline Fused2Geom fused2_geom(int m, int R = 64, int cap = C
 // 1: 9.03; var-TV 7.66 / 7.53 / - / 7.01 / 7.15), more parts for fewer column groups: slabs of 4096 rows x 512 / 1024 / 2048
 // columns 1.38 / 2.57 / 4.67 ms with >= 1024 tasks, 1.31 / 2.49 / 4.58 with >= 256 (4, 2, 2 parts).
 // The 4-wave kernels keep 8 (k_mf_fused_curv: no difference; k_var_lazy_curv: 7.81 ms with 8, 8.31 with 2, 8.87 with 1).
-__host__ __device__ inline int fused2_cap(int colgroups, int waves) {
+__host__ __device__ inline int fused2_cap(int colgroups, int waves, int forced = 0) {
     if (waves != 8) return CP_FUSED_PARTS;
+    if (forced > 0) return forced;        // CP_TUNE_PARTS8 (MfParams::parts8)
     int p = 2;
 #ifndef CP_FUSED_MINTASKS8
 #define CP_FUSED_MINTASKS8 256     // one workgroup per CU
@@ -252,9 +253,9 @@ __host__ __device__ inline int fused2_cap(int colgroups, int waves) {
     while (p < CP_FUSED_PARTS && (long long)p * colgroups < CP_FUSED_MINTASKS8) p *= 2;
     return p;
 }
-__host__ __device__ inline long long fused2_tasks(int m, int nl, int cw = 1, int waves = CP_WAVES) {
+__host__ __device__ inline long long fused2_tasks(int m, int nl, int cw = 1, int waves = CP_WAVES, int forced = 0) {
     const int colgroups = (nl + waves * cw - 1) / (waves * cw);
-    return (long long)fused2_geom(m, 64 / cw, fused2_cap(colgroups, waves)).parts * colgroups;
+    return (long long)fused2_geom(m, 64 / cw, fused2_cap(colgroups, waves, forced)).parts * colgroups;
 }
 
 // ---- hand-over of own-pixel results between the waves of a workgroup (no workgroup barrier) --------------------------------
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_tv(MfPa
     maxs[DM_Y1 - CP_NSUM] = 0.0; maxs[DM_S1 - CP_NSUM] = 0.0; maxs[PM_VL - CP_NSUM] = 0.0;
     double4_t acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 
-    const Fused2Geom GM = fused2_geom(m, R, fused2_cap((P.nl + NWV * CW - 1) / (NWV * CW), NWV));
+    const Fused2Geom GM = fused2_geom(m, R, fused2_cap((P.nl + NWV * CW - 1) / (NWV * CW), NWV, P.parts8));
     static_assert(!KS || (CW == 1 && NWV == CP_WAVES && !LINEAR), "KS: one column per workgroup of 4 waves");
     const int ntasks = KS ? GM.parts * P.nl : GM.parts * ((P.nl + NWV * CW - 1) / (NWV * CW));
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {

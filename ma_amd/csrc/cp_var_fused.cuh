@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_var_lazy_tv(MfPa
     for (int a = 0; a < CP_NMAX; ++a) maxs[a] = -1.0e300;
     maxs[DM_S1 - CP_NSUM] = 0.0;
 
-    const Fused2Geom GM = fused2_geom(m, 64, fused2_cap((P.nl + NWV - 1) / NWV, NWV));
+    const Fused2Geom GM = fused2_geom(m, 64, fused2_cap((P.nl + NWV - 1) / NWV, NWV, P.parts8));
     const int ntasks = GM.parts * ((P.nl + NWV - 1) / NWV);
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
         const int cg = task / GM.parts, pt = task - cg * GM.parts;
