@@ -267,6 +267,27 @@ __device__ __forceinline__ void bst(cp_rsrc r, unsigned voff, unsigned soff, dou
     else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r, voff, soff, 2);
 }
 
+// two consecutive elements per lane (16 bytes in fp64 storage, 8 in fp32): k_curv_y2_r2
+typedef unsigned int cp_u4 __attribute__((ext_vector_type(4)));
+template <typename S>
+struct cp_pair { S a, b; };
+// The loaded bits are reinterpreted as the pair in one bit_cast. (Taking the two halves of the b64 builtin's result as vector
+// elements -- cp_u2 v = load; v.x, v.y -- compiled to ONE buffer_load_dword with both halves equal on this toolchain.)
+template <typename S, int CACHE>
+__device__ __forceinline__ cp_pair<S> bld2_raw(cp_rsrc r, unsigned voff) {
+    if constexpr (sizeof(S) == 8) return __builtin_bit_cast(cp_pair<S>, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0u, CACHE));
+    else return __builtin_bit_cast(cp_pair<S>, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0u, CACHE));
+}
+template <typename S>
+__device__ __forceinline__ void bst2(cp_rsrc r, unsigned voff, double a, double b) {            // nt streaming store
+    if constexpr (sizeof(S) == 8) {
+        const cp_u2 lo = __builtin_bit_cast(cp_u2, a), hi = __builtin_bit_cast(cp_u2, b);
+        __builtin_amdgcn_raw_buffer_store_b128(cp_u4{lo.x, lo.y, hi.x, hi.y}, r, voff, 0u, 2);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b64(cp_u2{__builtin_bit_cast(unsigned, (float)a), __builtin_bit_cast(unsigned, (float)b)}, r, voff, 0u, 2);
+    }
+}
+
 // sqrt(x) and 1/sqrt(x) from one v_rsq_f64 and the Goldschmidt / residual steps of the compiler's own f64 sqrt
 // expansion, without its range scaling: arguments here are sums of squares of image-scale quantities. Below 1e-280
 // (in practice: exactly 0) both results are 0.

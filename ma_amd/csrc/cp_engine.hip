@@ -106,6 +106,7 @@ struct cp_engine {
     int fused_ka = 1;    // use the K <= 4 / 8 / 12 instantiations of k_mf_fused_tv (CP_TUNE_FUSED_KA=0: always 16)
     int nblk_fused = 0;  // grid of k_mf_fused_tv / k_mf_fused_curv (2 workgroups per CU resident: two LDS tiles per wave)
     int nblk_y2 = 0;     // grid of k_curv_y2
+    bool y2_r2 = false;  // k_curv_y2_r2 (two rows per lane; m even)
     int curv_waves = CP_WAVES, nblk_curv = 0;   // wavefronts (adjacent columns) per workgroup of k_mf_fused_curv and its grid (CP_TUNE_CURV_WAVES = 4 | 8)
     bool curv_fused = false;   // NN-curvature on k_mf_fused_curv + k_curv_y2 (CP_TUNE_CURV_SPLIT=1: the split passes)
     bool linearized = false, has_nu = false, has_images = false;
@@ -434,7 +435,12 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         h->var_fused = var && h->nl == h->d.n_global;
         if (const char *ev = getenv("CP_TUNE_VAR_SPLIT")) { if (atoi(ev) != 0) h->var_fused = false; }
         if (const char *ev = getenv("CP_TUNE_CURV_SPLIT")) { if (atoi(ev) != 0) h->curv_fused = false; }
-        if (mf) h->nblk_y2 = (int)std::min<long long>((curv_y2_tasks(h->m, h->nl, h->K) + 7) / 8 * 8, CP_FUSED_MAXGRID);
+        if (mf) {
+            // two rows per lane (16-byte accesses) where a column still gives every wave of a workgroup its 128 rows
+            h->y2_r2 = (h->m % 2 == 0) && h->m >= 512;
+            if (const char *ev = getenv("CP_TUNE_Y2_R2")) h->y2_r2 = (atoi(ev) != 0) && (h->m % 2 == 0);
+            h->nblk_y2 = (int)std::min<long long>((curv_y2_tasks(h->m, h->nl, h->K, h->y2_r2 ? 512 : 256) + 7) / 8 * 8, CP_FUSED_MAXGRID);
+        }
         if (const char *ev = getenv("CP_TUNE_FUSED_KA")) h->fused_ka = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_PW_SPLIT")) h->pw_split = atoi(ev) != 0;
         if (const char *ev = getenv("CP_TUNE_TIME_ALL")) h->time_all = atoi(ev) != 0;
@@ -1087,6 +1093,7 @@ static void launch_curv_t(cp_engine *h, const MfParams &P, const double *xp, dou
 template <typename S>
 static void launch_curv_y2_t(cp_engine *h, const MfParams &P, const double *xc, const double *xp, const double *pc, double *pn) {
     auto kern = (h->d.bc == CP_BC_NEUMANN) ? k_curv_y2<S, true> : k_curv_y2<S, false>;
+    if (h->y2_r2) kern = (h->d.bc == CP_BC_NEUMANN) ? k_curv_y2_r2<S, true> : k_curv_y2_r2<S, false>;
     hipLaunchKernelGGL(kern, dim3(h->nblk_y2), dim3(CP_BLOCK), 0, h->stream, P, (const S *)xc, (const S *)xp, (const S *)pc, (S *)pn,
                        (const CpCtrl *)h->ctrl, h->part);
 }

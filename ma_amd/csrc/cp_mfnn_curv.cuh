@@ -219,10 +219,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_curv(Mf
 #define CP_Y2_MINTASKS 16384
 #endif
 struct CurvY2Geom { int rblocks, strips, strips8, strip_w, fgroups, fields_per_group; };
-__host__ __device__ inline CurvY2Geom curv_y2_geom(int m, int nl, int K) {
+__host__ __device__ inline CurvY2Geom curv_y2_geom(int m, int nl, int K, int rows_per_block = 256) {
     CurvY2Geom G;
-    G.rblocks = (m + 255) / 256;
-    G.strip_w = nl < 32 ? nl : 32;
+    G.rblocks = (m + rows_per_block - 1) / rows_per_block;
+#ifndef CP_Y2_STRIP
+#define CP_Y2_STRIP 32
+#endif
+    G.strip_w = nl < CP_Y2_STRIP ? nl : CP_Y2_STRIP;
     G.strips = (nl + G.strip_w - 1) / G.strip_w;
     G.fgroups = 1;
     while ((long long)G.rblocks * G.strips * G.fgroups < CP_Y2_MINTASKS && G.fgroups < 2 * K) G.fgroups *= 2;
@@ -233,13 +236,16 @@ __host__ __device__ inline CurvY2Geom curv_y2_geom(int m, int nl, int K) {
 }
 // task ids: strip index mod 8 fastest (= the XCD, workgroups are dealt round robin), then the row block: vertically
 // adjacent row blocks of one strip are consecutive workgroups of one XCD and share the rows between them in its L2
-__host__ __device__ inline long long curv_y2_tasks(int m, int nl, int K) {
-    const CurvY2Geom G = curv_y2_geom(m, nl, K);
+__host__ __device__ inline long long curv_y2_tasks(int m, int nl, int K, int rows_per_block = 256) {
+    const CurvY2Geom G = curv_y2_geom(m, nl, K, rows_per_block);
     return 8LL * G.rblocks * G.strips8 * G.fgroups;
 }
 
+#ifndef CP_Y2_WPE
+#define CP_Y2_WPE 1         // waves per SIMD the register allocation has to leave room for (launch bounds)
+#endif
 template <typename S, bool NEUMANN, int CB = CP_Y2_CB>
-__global__ __launch_bounds__(CP_BLOCK) void k_curv_y2(MfParams P, const S *__restrict__ xc, const S *__restrict__ xo,
+__global__ __launch_bounds__(CP_BLOCK, CP_Y2_WPE) void k_curv_y2(MfParams P, const S *__restrict__ xc, const S *__restrict__ xo,
                                                       const S *__restrict__ pin, S *__restrict__ pout,
                                                       const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
     __shared__ double red[CP_WAVES * CP_NSCAL];
@@ -336,6 +342,124 @@ __global__ __launch_bounds__(CP_BLOCK) void k_curv_y2(MfParams P, const S *__res
                         if (f & 1) sums[DS_BSY] += n0 * rs; else sums[DS_BSX] += n0 * rs;
                     }
                     an_m = an_c; ao_m = ao_c; an_c = an_p; ao_c = ao_p;
+                }
+            }
+        }
+    }
+    block_reduce_store<CP_NSUM, CP_NMAX>(sums, maxs, red, part + (size_t)blockIdx.x * CP_PSTRIDE);
+}
+
+// ---- k_curv_y2_r2: the same pass with TWO rows per lane (m even) --------------------------------------------------------------
+// A lane owns rows (i, i+1), a wave 128 rows, a workgroup 512: every wave-wide access is one 1 KB run of 16 bytes per lane in
+// fp64 storage (8 in fp32), the access shape the streaming copy needs for its 6.5 TB/s (8 bytes per lane: 5.7), and the two rows
+// outside a segment are fetched once per 128 rows instead of once per 64. (i+1) of the lane's first row and (i-1) of its second
+// are its own values; the other two come from lane +- 1 (lanes 0 and 63: one-lane loads). Arithmetic per pixel is that of
+// k_curv_y2, expression by expression.
+#ifndef CP_Y2R2_CB
+#define CP_Y2R2_CB 4
+#endif
+template <typename S, bool NEUMANN, int CB = CP_Y2R2_CB>
+__global__ __launch_bounds__(CP_BLOCK) void k_curv_y2_r2(MfParams P, const S *__restrict__ xc, const S *__restrict__ xo,
+                                                         const S *__restrict__ pin, S *__restrict__ pout,
+                                                         const CpCtrl *__restrict__ ctrl, double *__restrict__ part) {
+    __shared__ double red[CP_WAVES * CP_NSCAL];
+    if (ctrl->stop) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = P.K, m = P.m;
+    const size_t fs = (size_t)P.fs;
+    const double sigma = P.sigma, theta = P.theta, inv_sigma = 1.0 / P.sigma;
+    const double ih1 = P.inv_h1 * P.inv_h1, ih2 = P.inv_h2 * P.inv_h2;
+    const double den = 1.0 + P.mu2 * inv_sigma;
+    constexpr unsigned ES = (unsigned)sizeof(S), kNone = 0xFFFFFFFFu;
+    const unsigned mb = ES * (unsigned)m;
+    double sums[CP_NSUM], maxs[CP_NMAX];
+#pragma unroll
+    for (int a = 0; a < CP_NSUM; ++a) sums[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < CP_NMAX; ++a) maxs[a] = 0.0;
+
+    const CurvY2Geom GM = curv_y2_geom(m, P.nl, K, 512);
+    const int ntasks = 8 * GM.rblocks * GM.strips8 * GM.fgroups;
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        int q = task >> 3;
+        const int rb = q % GM.rblocks;
+        q /= GM.rblocks;
+        const int cs = (q % GM.strips8) * 8 + (task & 7), fg = q / GM.strips8;
+        const int ii = rb * 512 + wave * 128 + 2 * lane;             // rows ii, ii + 1 (m is even: both exist or neither)
+        if (cs >= GM.strips || rb * 512 + wave * 128 >= m) continue;   // wave-uniform
+        const bool valid = ii < m;
+        const int i = min(ii, m - 2);
+        const bool first_i = (i == 0), last_i = (i + 1 == m - 1);    // of the lane's first / second row
+        const int j0 = cs * GM.strip_w, j1 = min(j0 + GM.strip_w, P.nl);
+        const int f0 = fg * GM.fields_per_group, f1 = min(f0 + GM.fields_per_group, 2 * K);
+        const bool edge_dn = (lane == 0) && !first_i, edge_up = (lane == 63) && valid && !last_i;
+        for (int f = f0; f < f1; ++f) {
+            const cp_rsrc r_un = mk_rsrc(xc + (size_t)f * fs), r_uo = mk_rsrc(xo + (size_t)f * fs);
+            const cp_rsrc r_yi = mk_rsrc(pin + ((size_t)K + f) * fs), r_yo = mk_rsrc(pout + ((size_t)K + f) * fs);
+            unsigned off = ES * (unsigned)((j0 + 1) * m + i);     // (i, j0)
+            cp_pair<S> t;
+            double an_m[2], ao_m[2], an_c[2], ao_c[2];
+            t = bld2_raw<S, 0>(r_un, off - mb); an_m[0] = (double)t.a; an_m[1] = (double)t.b;   // column j0 - 1
+            t = bld2_raw<S, 0>(r_uo, off - mb); ao_m[0] = (double)t.a; ao_m[1] = (double)t.b;
+            t = bld2_raw<S, 2>(r_un, off); an_c[0] = (double)t.a; an_c[1] = (double)t.b;
+            t = bld2_raw<S, 2>(r_uo, off); ao_c[0] = (double)t.a; ao_c[1] = (double)t.b;
+            for (int jb = j0; jb < j1; jb += CB, off += CB * mb) {
+                cp_pair<S> rp_n[CB], rp_o[CB], rv[CB];
+                S ru_n[CB], ru_o[CB], rd_n[CB], rd_o[CB];
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const bool in = jb + c < j1;                  // wave-uniform
+                    const unsigned o = off + (unsigned)c * mb;
+                    const unsigned o_p = in ? o + mb : kNone, o_c = in ? o : kNone;
+                    if (c + 1 < CB) { rp_n[c] = bld2_raw<S, 2>(r_un, o_p); rp_o[c] = bld2_raw<S, 2>(r_uo, o_p); }
+                    else { rp_n[c] = bld2_raw<S, 0>(r_un, o_p); rp_o[c] = bld2_raw<S, 0>(r_uo, o_p); }
+                    rv[c] = bld2_raw<S, 2>(r_yi, o_c);
+                    const unsigned o_u = (in && edge_up) ? o + 2 * ES : kNone, o_d = (in && edge_dn) ? o - ES : kNone;
+                    ru_n[c] = bld_raw<S>(r_un, o_u); ru_o[c] = bld_raw<S>(r_uo, o_u);
+                    rd_n[c] = bld_raw<S>(r_un, o_d); rd_o[c] = bld_raw<S>(r_uo, o_d);
+                }
+                if (sizeof(S) == 4) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const int j = jb + c;
+                    const bool in = j < j1;
+                    const int jg = P.j_off + j;
+                    const bool first_j = (jg == 0), last_j = (jg == P.n_global - 1);
+                    const double an_p[2] = {(double)rp_n[c].a, (double)rp_n[c].b}, ao_p[2] = {(double)rp_o[c].a, (double)rp_o[c].b};
+                    const double v[2] = {(double)rv[c].a, (double)rv[c].b};
+                    double an_u = __shfl(an_c[0], lane + 1), ao_u = __shfl(ao_c[0], lane + 1);   // (i + 2, j): above the second row
+                    double an_d = __shfl(an_c[1], lane - 1), ao_d = __shfl(ao_c[1], lane - 1);   // (i - 1, j): below the first row
+                    if (edge_up) { an_u = (double)ru_n[c]; ao_u = (double)ru_o[c]; }
+                    if (edge_dn) { an_d = (double)rd_n[c]; ao_d = (double)rd_o[c]; }
+                    double n0[2];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const bool fi = (r == 0) && first_i, li = (r == 1) && last_i;
+                        const double uc0 = an_c[r], ub0 = an_c[r] + theta * (an_c[r] - ao_c[r]);
+                        const bool have[4] = {!fi, !li, !first_j, !last_j};
+                        const double na[4] = {r == 0 ? an_d : an_c[0], r == 0 ? an_c[1] : an_u, an_m[r], an_p[r]};
+                        const double no[4] = {r == 0 ? ao_d : ao_c[0], r == 0 ? ao_c[1] : ao_u, ao_m[r], ao_p[r]};
+                        double nb[4], nbb[4];
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            nb[d] = have[d] ? na[d] : (NEUMANN ? uc0 : 0.0);
+                            nbb[d] = have[d] ? na[d] + theta * (na[d] - no[d]) : (NEUMANN ? ub0 : 0.0);
+                        }
+                        const double lapc = (nb[0] + nb[1] - 2.0 * uc0) * ih1 + (nb[2] + nb[3] - 2.0 * uc0) * ih2;
+                        const double lapb = (nbb[0] + nbb[1] - 2.0 * ub0) * ih1 + (nbb[2] + nbb[3] - 2.0 * ub0) * ih2;
+                        const double t0 = v[r] + sigma * lapb;
+                        n0[r] = rnd<S>(t0 - sigma * ((t0 * inv_sigma) / den));               // NNE/SSD.m:60-61 with :43 (g = 0)
+                        if (valid && in) {
+                            sums[DS_F2] += lapc * lapc;                                       // NNE/SSD.m:48 (g = 0)
+                            const double z0 = n0[r] / P.mu2;
+                            sums[DS_F2S] += z0 * z0;                                          // NNE/SSD.m:66-67
+                            const double rs = lap_rowsum(NEUMANN, fi, li, first_j, last_j, ih1, ih2);
+                            if (f & 1) sums[DS_BSY] += n0[r] * rs; else sums[DS_BSX] += n0[r] * rs;
+                        }
+                    }
+                    bst2<S>(r_yo, (valid && in) ? off + (unsigned)c * mb : kNone, n0[0], n0[1]);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { an_m[r] = an_c[r]; ao_m[r] = ao_c[r]; an_c[r] = an_p[r]; ao_c[r] = ao_p[r]; }
                 }
             }
         }

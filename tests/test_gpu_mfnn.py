@@ -369,3 +369,59 @@ def test_more_than_16_images_against_oracle(reg, bc, m, n, k):
     np.testing.assert_allclose(dh[:, :5], dhr[:, :5], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(ph[:, 5:], phr[:, 5:], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(dh[:, 5:], dhr[:, 5:], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("model,bc,m,n,k,fp32", [("nn", "dirichlet", 2, 67, 1, False), ("nn", "neumann", 70, 55, 5, False),
+                                                  ("nn", "dirichlet", 130, 9, 3, False), ("nn", "neumann", 640, 7, 2, False),
+                                                  ("nn", "dirichlet", 258, 35, 4, True), ("var", "dirichlet", 132, 33, 6, False),
+                                                  ("var", "neumann", 516, 5, 3, True)])
+def test_curv_y2_two_rows_per_lane(monkeypatch, model, bc, m, n, k, fp32):
+    """k_curv_y2_r2 (two rows per lane, 16-byte accesses; the default from 512 even rows on) forced at small and ragged even
+    sizes -- a lone pair of rows, a wave with 3 / 35 live lanes, a second 512-row block of 128 rows, strips narrower than the
+    load group -- for the NN-curvature and the variance-curvature model, both boundary conditions, fp64 and fp32 storage:
+    against the one-row kernel (same arithmetic per pixel; the partial sums associate differently) and, for NN-curvature in
+    fp64, against the numpy oracle."""
+    from ma_amd import engine as E, synth
+    from oracle import drivers as od
+    from oracle.chambolle_pock import chambolle_pock as cp_ref
+    rng = np.random.default_rng(11 * m + n)
+    imgs = synth.dynamic_test_image(m, n, k).numpy() if min(m, n) >= 8 else rng.random((k, m, n))
+    u0 = 0.4 * rng.standard_normal((k, 2, n * m))
+    omega = [0.0, float(m), 0.0, float(n)]
+    h = (1.0, 1.0)
+    mu = 20.0 if model == "nn" else 5.0
+    tau = sigma = 0.1
+    iters = 25
+    kmn = k * m * n
+    flags = E.FLAG_FP32 if fp32 else 0
+    out = {}
+    for r2 in ("0", "1"):
+        monkeypatch.setenv("CP_TUNE_Y2_R2", r2)
+        eng = E.Engine(E.MODEL_MF_NN_CURV if model == "nn" else E.MODEL_VAR_CURV, m, n, k=k, bc=bc, h=h, omega=omega, mu=mu, flags=flags)
+        eng.set_images(np.concatenate([imgs[i].reshape(-1, order="F") for i in range(k)]))
+        x0 = np.concatenate([u0.reshape(-1), np.zeros(kmn)]) if model == "nn" else u0.reshape(-1)
+        eng.set_primal(x0)
+        eng.linearize()
+        if model == "nn":
+            x0[2 * kmn:] = 0.5 * eng.get_linearization()[0]
+            eng.set_primal(x0)
+            eng.linearize()
+            eng.set_nu(1.5 * k)
+        y0 = 0.01 * np.random.default_rng(3).standard_normal((4 if model == "nn" else 3) * kmn)
+        eng.set_dual(y0)
+        eng.solve(1.0, tau, sigma, iters, 0.0)
+        out[r2] = (eng.primal(), eng.dual(), *eng.history(), x0, y0)
+        eng.close()
+    tol = 2e-5 if fp32 else 1e-12
+    for a, b in zip(out["0"][:4], out["1"][:4]):
+        np.testing.assert_allclose(b, a, rtol=tol, atol=tol * max(1.0, np.abs(a).max()))
+    if model == "nn" and not fp32:
+        u0_ref = np.transpose(u0, (2, 1, 0))
+        A, b, T_u, gs = od.mf_nn_problem([imgs[i] for i in range(k)], u0_ref, h, omega, "curvature", bc)
+        x0, y0 = out["1"][4], out["1"][5]
+        Fh = lambda y, c, nargout: od.mf_nn_F(y, b, k, h, mu, 1.5 * k, sigma, c, nargout, "curvature")
+        Gh = lambda x, c, nargout: od.mf_nn_G(x, (m, n, k), c, nargout)
+        xr, yr, phr, dhr = cp_ref(Fh, Gh, A, x0, y0, 1.0, tau, sigma, iters, 0.0)
+        assert _rel(out["1"][0], xr) < TOL and _rel(out["1"][1], yr) < TOL
+        np.testing.assert_allclose(out["1"][2][:, :5], phr[:, :5], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(out["1"][3][:, :5], dhr[:, :5], rtol=1e-9, atol=1e-9)
