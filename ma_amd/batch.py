@@ -84,3 +84,35 @@ def tv_registration_batch(R, T, lam, tau, maxIter, numSteps, data_term="SSD", h=
     dist.all_gather_object(parts, (p0, u_loc, it_loc))
     parts.sort(key=lambda t: t[0])
     return np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])
+
+
+MULTI_IMAGE_DRIVERS = ("mf_nn_tv_registration_no_ref_ml", "mf_nn_curvature_registration_no_ref_ml",
+                       "var_tv_registration_no_ref_ml", "var_curvature_registration_no_ref_ml",
+                       "mf_nn_tv_registration_no_ref", "var_tv_registration_no_ref")
+
+
+def multi_image_registration_batch(datasets, optPara, driver="mf_nn_tv_registration_no_ref_ml", device=0, gather=True, **kw):
+    """A batch of independent multi-image registrations (one image sequence per entry of `datasets`, each a list of k
+    m x n images; sizes may differ between entries) sharded over the ranks like the pairwise batch above: rank r runs the
+    named driver of ma_amd.drivers (= the reference's NNE/<driver>.m, one call per data set) on the contiguous range
+    shard_range(P, world, r), one after the other on its GPU -- a multi-image problem of useful size fills the GPU by
+    itself (one engine handle per problem: cp_create takes batch = 1 for these models), so problems of one rank gain
+    nothing from running side by side. No data-path collective. Returns the list of the drivers' result tuples, for all
+    data sets on every rank (gather=True) or for the local shard together with (p0, p1)."""
+    from . import drivers as D
+    import torch.distributed as dist
+    if driver not in MULTI_IMAGE_DRIVERS:
+        raise ValueError(f"unknown multi-image driver {driver!r}")
+    fn = getattr(D, driver)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    p0, p1 = shard_range(len(datasets), world, rank)
+    local = [fn(datasets[p], optPara, device=device, **kw) for p in range(p0, p1)]
+    if world == 1:
+        return local
+    if not gather:
+        return local, (p0, p1)
+    parts = [None] * world
+    dist.all_gather_object(parts, (p0, local))
+    parts.sort(key=lambda t: t[0])
+    return [res for _, loc in parts for res in loc]

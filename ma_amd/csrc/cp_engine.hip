@@ -386,6 +386,9 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             HIPCHK(hipMalloc(&h->g, sizeof(double) * gN));
             HIPCHK(hipMalloc(&h->b, sizeof(double) * bN));
         }
+        if (getenv("CP_DEBUG_ADDR"))
+            fprintf(stderr, "cpengine addr X %p %p P %p %p g %p b %p\n", (void *)h->X[0], (void *)h->X[1], (void *)h->P[0], (void *)h->P[1],
+                    (void *)h->g, (void *)h->b);
         for (int a = 0; a < 2; ++a) {
             HIPCHK(hipMemsetAsync(h->X[a], 0, sizeof(double) * h->xN, h->stream));
             HIPCHK(hipMemsetAsync(h->P[a], 0, sizeof(double) * h->pN, h->stream));

@@ -19,6 +19,17 @@ def test_batch_shards_match_single_handle(world, P, fp32):
     assert r.returncode == 0 and "batch shards == single handle" in r.stdout
 
 
+def test_multi_image_batch_shards_match_the_drivers():
+    """ma_amd.batch.multi_image_registration_batch: image sequences of different sizes (one with 18 images: the general
+    K > 16 path) sharded over 2 gloo ranks, mf_nn and variance drivers, equal to the drivers called one by one (bitwise)"""
+    env = dict(os.environ, BATCH_P="2", BATCH_FP32="0", BATCH_MULTI="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29446", os.path.join(ROOT, "tests", "batch_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "multi-image batch == drivers one by one" in r.stdout
+
+
 def test_bench_batch_workload_two_ranks():
     """bench.py --workload batch with 2 ranks (gloo on one GPU): one JSON line from rank 0, all problems counted"""
     import json

@@ -90,6 +90,19 @@ def _batch_worker(rank, world, port, results):
     ok = np.array_equal(u, want) and its.shape == (P, 2)
     u_loc, _, (p0, p1) = batch.tv_registration_batch(R, T, 1.0, 1.0, 5, 2, gather=False)
     ok &= (p0, p1) == batch.shard_range(P, world, rank) and np.array_equal(u_loc, want[p0:p1])
+    # multi-image batch: the driver is looked up by name in ma_amd.drivers; a stub stands in for the GPU driver
+    from ma_amd import drivers
+    drivers.var_tv_registration_no_ref_ml = lambda imgs, opt, device=0, **kw: (len(imgs), float(np.sum(imgs[0])) * opt["mu"])
+    data = [[rng.standard_normal((3 + p, 2)) for _ in range(2 + p % 3)] for p in range(5)]
+    res = batch.multi_image_registration_batch(data, dict(mu=2.0), "var_tv_registration_no_ref_ml")
+    ok &= res == [(len(d), float(np.sum(d[0])) * 2.0) for d in data]
+    loc, (q0, q1) = batch.multi_image_registration_batch(data, dict(mu=2.0), "var_tv_registration_no_ref_ml", gather=False)
+    ok &= (q0, q1) == batch.shard_range(len(data), world, rank) and loc == res[q0:q1]
+    try:
+        batch.multi_image_registration_batch(data, {}, "no_such_driver")
+        ok = False
+    except ValueError:
+        pass
     results[rank] = bool(ok)
     dist.destroy_process_group()
 
