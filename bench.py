@@ -113,9 +113,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=0,
                     help="timed regions of exactly --steps iterations each (barrier + synchronize on both sides of every one); "
-                         "the line reports the median region, `samples_ms_per_step` lists all (SURVEY.md 8d: median of 5)")
+                         "the line reports the median region, `samples_ms_per_step` lists all. Default (0): at least 5 and "
+                         "enough for 200 timed iterations in all (SURVEY.md 8d: >= 200 iterations after warm-up, median of 5)")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--cols", type=int, default=0, help="image columns (default: --size); a slab-shaped problem for tuning")
     ap.add_argument("--k", type=int, default=16)
@@ -149,8 +150,29 @@ def self_launch(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CP_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # wait for rank 0's output, but do not outlive a rank that died: the survivors would sit in the rendezvous or in a
+    # collective until its time-out. The children are stopped by their own PIDs.
+    out0 = None
+    while out0 is None:
+        try:
+            out0, _ = procs[0].communicate(timeout=1.0)
+        except subprocess.TimeoutExpired:
+            if any(p.poll() not in (None, 0) for p in procs[1:]):
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                try:
+                    out0, _ = procs[0].communicate(timeout=30.0)
+                except subprocess.TimeoutExpired:
+                    procs[0].kill()
+                    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=120.0))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
     lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
     for ln in lines[-1:]:
         print(ln, flush=True)
@@ -385,7 +407,7 @@ def main():
     # one run of warmup + repeats * steps iterations: start-up (x_old = x0, the first dual step) before the warm-up, then
     # `repeats` timed regions of exactly `steps` CP iterations each, every one bracketed by barrier + synchronize on both
     # sides and reduced with MAX over the ranks; the state is brought back to canonical form after the last one
-    reps = max(1, args.repeats)
+    reps = args.repeats if args.repeats > 0 else max(5, -(-200 // max(1, args.steps)))
     solver.iterate_begin(1.0, tau, sigma, args.warmup + reps * args.steps)
     solver.iterate_steps(args.warmup)
     solver.sync()

@@ -41,7 +41,8 @@ def test_bench_line_fields():
     assert abs(rf["algorithmic_frac"] - rf["algorithmic_achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] <= 1.0
     # the kernel name comes from the library; no PMC measurement is committed for this small shape
     assert rf["kernel"].startswith("k_mf_fused_tv<double, false, false, 4,") and rf["traffic"] is None and rf["hbm_frac"] is None
-    assert out["repeats"] == 5 and len(out["samples_ms_per_step"]) == 5 and out["handover_fallbacks"] == 0
+    # default protocol: at least 5 regions and at least 200 timed iterations in all -> 40 regions of 5 steps here
+    assert out["repeats"] == 40 and len(out["samples_ms_per_step"]) == 40 and out["handover_fallbacks"] == 0
     assert out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
     assert rf["measured_copy_GBps"]["16B_per_lane"] > 5500.0      # the one-element-per-thread copy (guide: 6.29 TB/s)
     cb = out["cpu_baseline"]
