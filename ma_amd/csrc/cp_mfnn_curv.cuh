@@ -91,36 +91,61 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_curv(Mf
             const bool want = valid && !last_i;                    // y2_n at (i+1, j) is used
             const bool from_carry = want && lane == 63 && sg < seg_hi;
             const bool reload = want && lane == 63 && sg == seg_hi;
-            const bool any_reload = __any(reload);                 // wave-uniform: first step of a part below the image's top
             const double *cin = carry + (par ^ 1) * CP_KMAX * 2;
             double *cout_ = carry + par * CP_KMAX * 2;
             const double vmask = valid ? 1.0 : 0.0;
+            // Round 3: the per-image body is ONE basic block. Every load of the image is issued first, through buffer descriptors
+            // (uniform field base in SGPRs + one 32-bit lane offset; the second field of a pair through the uniform offset), and
+            // the stores are unconditional: positions that do not exist -- lanes past the end of the column, (i-1, j) in all
+            // lanes but the first, the one-lane (i+1, j) load at the top of a part -- carry the offset 2^32-1 and are dropped by
+            // the range check. Before, the second y2 component was loaded after the first had been consumed and every image
+            // ended in a full wait that included its own stores (branches around memory operations hide the counts from the
+            // wait-count pass): three dependent round trips per image.
+            constexpr unsigned kNone = 0xFFFFFFFFu;
+            const unsigned offv = valid ? off : kNone;
+            const unsigned off_re = reload ? off + ES : kNone;
+            const unsigned fsb = (unsigned)(fs * ES);               // fields of the multi-image models stay below 2 GiB (cp_create)
             for (int k = 0; k < K; ++k) {
-                const S *y1k = pin + (size_t)k * fs, *y2k = pin + ((size_t)K + 2 * (size_t)k) * fs;
-                const S *gxk = g + 2 * (size_t)k * fs, *uxk = xo + 2 * (size_t)k * fs;
+                const cp_rsrc r_y1 = mk_rsrc(pin + (size_t)k * fs), r_y2 = mk_rsrc(pin + ((size_t)K + 2 * (size_t)k) * fs);
+                const cp_rsrc r_g = mk_rsrc(g + 2 * (size_t)k * fs), r_b = mk_rsrc(b + (size_t)k * fs);
+                const cp_rsrc r_xo = mk_rsrc(xo + 2 * (size_t)k * fs), r_xn = mk_rsrc(xn + 2 * (size_t)k * fs);
+                const cp_rsrc r_y1o = mk_rsrc(pout + (size_t)k * fs);
+                const S q_y1 = bld_raw<S>(r_y1, off), q_gx = bld_raw<S>(r_g, off), q_gy = bld_raw<S>(r_g, off, fsb);
+                const S q_b = bld_raw_stream<S>(r_b, off);
+                const S q_uxo = bld_raw_stream<S>(r_xo, off), q_uyo = bld_raw_stream<S>(r_xo, off, fsb);
+                S q_w0[2], q_wim[2], q_wjm[2], q_wjp[2], q_wre[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const unsigned so = c ? fsb : 0u;
+                    q_w0[c] = bld_raw<S>(r_y2, off, so);
+#if CP_FUSED_SHF
+                    q_wim[c] = bld_raw<S>(r_y2, (off - ES) | off_l0, so);   // lanes 1..63: out of range, dropped
+#else
+                    q_wim[c] = bld_raw<S>(r_y2, off - ES, so);
+#endif
+                    q_wjm[c] = bld_raw<S>(r_y2, off - mb, so);
+                    q_wjp[c] = bld_raw<S>(r_y2, off + mb, so);
+                    q_wre[c] = bld_raw<S>(r_y2, off_re, so);                // (i+1, j) for lane 63 at the top of a part
+                }
+                if (sizeof(S) == 4) __builtin_amdgcn_sched_barrier(0);
                 const double Lc = tileA[k * CP_TS + lane], Lbar = tileB[k * CP_TS + lane];
-                const double y1 = ldo(y1k, off);
-                const double gx = ldo(gxk, off), gy = ldo(gxk + fs, off);
-                const double bb = ldo_stream(b + (size_t)k * fs, off);
-                const double uxo_ = ldo_stream(uxk, off), uyo_ = ldo_stream(uxk + fs, off);
+                const double y1 = (double)q_y1, gx = (double)q_gx, gy = (double)q_gy, bb = (double)q_b;
+                const double uxo_ = (double)q_uxo, uyo_ = (double)q_uyo;
                 double lap[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const S *f = y2k + (size_t)c * fs;
-                    const double w0 = ldo(f, off);
+                    const double w0 = (double)q_w0[c];
 #if CP_FUSED_SHF
-                    const double wim0 = bld<S>(mk_rsrc(f), (off - ES) | off_l0);   // lanes 1..63: out of range, dropped
                     const double wsh = lane_shr1<double>(w0);         // evaluated by every lane, before the select
-                    const double wim = (lane == 0) ? wim0 : wsh;
+                    const double wim = (lane == 0) ? (double)q_wim[c] : wsh;
 #else
-                    const double wim = ldo(f, off, -(int)ES);
+                    const double wim = (double)q_wim[c];
 #endif
-                    const double wjm = ldo(f, off - mb), wjp = ldo(f, off + mb);
+                    const double wjm = (double)q_wjm[c], wjp = (double)q_wjp[c];
+                    const double cv = cin[2 * k + c];                 // uniform address: one broadcast read
                     double wip = __shfl(w0, lane + 1);
-                    if (from_carry) wip = cin[2 * k + c];
-                    if (any_reload) {
-                        if (reload) wip = ldo(f, off, (int)ES);
-                    }
+                    wip = from_carry ? cv : wip;
+                    wip = reload ? (double)q_wre[c] : wip;
                     if (lane == 0) cout_[2 * k + c] = w0;
                     // NNE/discrete_laplacian.m:23-46: a missing neighbour is the centre value (neumann) or zero (dirichlet)
                     const double a0 = !first_i ? wim : (NEUMANN ? w0 : 0.0);
@@ -134,15 +159,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_curv(Mf
                 const double ux = rnd<S>((uxo_ - tau * vux) - cnx);    // NNE/mean_zero_indicator.m:50,53
                 const double uy = rnd<S>((uyo_ - tau * vuy) - cny);
                 const double wx = -vux, wy = -vuy;
-                S *uxo_k = xn + 2 * (size_t)k * fs;
-                if (valid) {
-                    sto(uxo_k, off, ux);
-                    sto(uxo_k + fs, off, uy);
-                    maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], wx);     // NNE/mean_zero_indicator.m:78-84
-                    maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], -wx);
-                    maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], wy);
-                    maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], -wy);
-                }
+                bst<S>(r_xn, offv, 0u, ux);
+                bst<S>(r_xn, offv, fsb, uy);
+                const double big = -1.0e300;
+                maxs[PM_WXMAX - CP_NSUM] = fmax(maxs[PM_WXMAX - CP_NSUM], valid ? wx : big);     // NNE/mean_zero_indicator.m:78-84
+                maxs[PM_WXMIN - CP_NSUM] = fmax(maxs[PM_WXMIN - CP_NSUM], valid ? -wx : big);
+                maxs[PM_WYMAX - CP_NSUM] = fmax(maxs[PM_WYMAX - CP_NSUM], valid ? wy : big);
+                maxs[PM_WYMIN - CP_NSUM] = fmax(maxs[PM_WYMIN - CP_NSUM], valid ? -wy : big);
                 sums[PS_WX] += vmask * wx;
                 const double uxb = ux + theta * (ux - uxo_), uyb = uy + theta * (uy - uyo_);
                 // ---- y1: SAD* (identical to k_mf_dual) ----------------------------------------------------------------
@@ -156,10 +179,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_curv(Mf
                 sums[DS_F1S] += vmask * (y1n * bb);                                   // :83
                 sums[DS_SGX] += vmask * (gx * y1n);
                 sums[DS_SGY] += vmask * (gy * y1n);
-                if (valid) {
-                    sto(pout + (size_t)k * fs, off, y1n);
-                    maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], fabs(y1n));
-                }
+                bst<S>(r_y1o, offv, 0u, y1n);
+                maxs[DM_Y1 - CP_NSUM] = fmax(maxs[DM_Y1 - CP_NSUM], valid ? fabs(y1n) : 0.0);
                 sums[DS_UX] += vmask * ux;
                 sums[DS_UY] += vmask * uy;
             }

@@ -194,10 +194,11 @@ __device__ __forceinline__ void fused_phase1(const MfParams &P, int K, bool vali
         const bool act = FULLK || (k < K);
         const double v = (valid && act) ? rnd<S>(a[k] - smb) : 0.0;
         tileA[k * CP_TS + lane] = v;
-        if (valid && act) {
-            sto(y3out + (size_t)k * fs, off, v);
-            sto(Lout + (size_t)k * fs, off, Lr[k]);
-        }
+        // unconditional (round 3): a lane past the end of the column / an image past K carries the offset 2^32-1, which the
+        // range check of the buffer store drops -- 2 x KA branches around stores less per step
+        const unsigned so = (valid && act) ? off : 0xFFFFFFFFu;
+        bst<S>(mk_rsrc(y3out + (size_t)k * fs), so, 0u, v);
+        bst<S>(mk_rsrc(Lout + (size_t)k * fs), so, 0u, Lr[k]);
     }
     wave_lds_sync();
     gram_tile_accum(tileA, acc1);
