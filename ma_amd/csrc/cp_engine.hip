@@ -79,7 +79,6 @@ struct cp_engine {
     size_t xN = 0, pN = 0;  // doubles per x / p buffer (all problems)
     double *X[2] = {nullptr, nullptr}, *P[2] = {nullptr, nullptr};
     double *g = nullptr, *b = nullptr, *Tu = nullptr, *img = nullptr, *imgR = nullptr;
-    double *arena = nullptr;   // CP_TUNE_ARENA: X, P, g, b carved out of one allocation (placement experiments)
     double *W[3] = {nullptr, nullptr, nullptr};   // W[2] = scratch
     double *xtmp = nullptr;
     double *bnd[2] = {nullptr, nullptr};     // NN-TV: boundary arrays of P[0], P[1] (cp_mfnn_fused.cuh: bnd_block), in the storage type
@@ -255,7 +254,6 @@ extern "C" int cp_destroy(cp_handle h) {
     if (h->red) hipFree(h->red);
     if (h->stage) hipFree(h->stage);
     if (h->vwarm) hipFree(h->vwarm);
-    if (h->arena) { hipFree(h->arena); h->X[0] = h->X[1] = h->P[0] = h->P[1] = h->g = h->b = nullptr; }
     double *ptrs[] = {h->X[0], h->X[1], h->P[0], h->P[1], h->g, h->b, h->Tu, h->img, h->imgR, h->W[0], h->W[1],
                       h->W[2], h->xtmp, h->vlazy[0], h->vlazy[1], h->bnd[0], h->bnd[1], h->part, h->part2, h->svout, h->hist_p, h->hist_d};
     for (double *p : ptrs)
@@ -367,28 +365,12 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         h->xN = (size_t)h->nxf * h->fs * h->batch;
         h->pN = (size_t)h->npf * h->fs * h->batch;
         const size_t gN = (size_t)2 * h->K * h->fs * h->batch, bN = (size_t)h->K * h->fs * h->batch;
-        if (const char *ev = getenv("CP_TUNE_ARENA")) {   // experiments: one allocation, <value> KB between the buffers
-            const size_t gap = (size_t)std::max(0, atoi(ev)) * 128;   // doubles
-            const size_t tot = 2 * (h->xN + h->pN) + gN + bN + 6 * gap;
-            HIPCHK(hipMalloc(&h->arena, sizeof(double) * tot));
-            double *q = h->arena;
-            h->X[0] = q; q += h->xN + gap;
-            h->P[0] = q; q += h->pN + gap;
-            h->X[1] = q; q += h->xN + gap;
-            h->P[1] = q; q += h->pN + gap;
-            h->g = q; q += gN + gap;
-            h->b = q;
-        } else {
-            for (int a = 0; a < 2; ++a) {
-                HIPCHK(hipMalloc(&h->X[a], sizeof(double) * h->xN));
-                HIPCHK(hipMalloc(&h->P[a], sizeof(double) * h->pN));
-            }
-            HIPCHK(hipMalloc(&h->g, sizeof(double) * gN));
-            HIPCHK(hipMalloc(&h->b, sizeof(double) * bN));
+        for (int a = 0; a < 2; ++a) {
+            HIPCHK(hipMalloc(&h->X[a], sizeof(double) * h->xN));
+            HIPCHK(hipMalloc(&h->P[a], sizeof(double) * h->pN));
         }
-        if (getenv("CP_DEBUG_ADDR"))
-            fprintf(stderr, "cpengine addr X %p %p P %p %p g %p b %p\n", (void *)h->X[0], (void *)h->X[1], (void *)h->P[0], (void *)h->P[1],
-                    (void *)h->g, (void *)h->b);
+        HIPCHK(hipMalloc(&h->g, sizeof(double) * gN));
+        HIPCHK(hipMalloc(&h->b, sizeof(double) * bN));
         for (int a = 0; a < 2; ++a) {
             HIPCHK(hipMemsetAsync(h->X[a], 0, sizeof(double) * h->xN, h->stream));
             HIPCHK(hipMemsetAsync(h->P[a], 0, sizeof(double) * h->pN, h->stream));
