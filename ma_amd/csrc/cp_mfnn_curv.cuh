@@ -24,9 +24,15 @@
 // columns per workgroup, no workgroup barrier in the loop. y2_n at (i+1, j) is lane+1's own value (lane 63: the value
 // lane 0 loaded one step earlier, through LDS; at the top of a part a load in lane 63 alone), at (i-1, j) one
 // element-shifted load, at (i, j-1) and (i, j+1) the lines the neighbouring waves stream.
-// Round 3: (i-1, j) is lane - 1's own value (cross-lane shift, lane_shr1) and one load in the segment's first lane instead
-// of an element-shifted wave-wide load that straddles five lines; NWV = 8 adjacent columns per workgroup (one workgroup per
-// CU) halves the (i, j +- 1) lines that belong to another workgroup.
+// Round 3: the per-image body is one basic block of buffer loads and range-dropped stores (below); NWV = 8 adjacent columns per
+// workgroup (one workgroup per CU, CP_TUNE_CURV_WAVES=8) would halve the (i, j +- 1) lines that belong to another workgroup but
+// measured slower (6.25 vs 6.0 ms); (i-1, j) by cross-lane shift is CP_CURV_SHF (off).
+// CP_CURV_SHF=1: (i-1, j) as lane - 1's value (lane_shr1) + one load in the first lane; measured after the per-image body became one
+// basic block: 6.03 / 6.58 ms against 5.97 / 6.49 with the element-shifted wave-wide load (the two placement modes of one box,
+// 4096^2 x 16) -- the shifted load is an L1 hit on lines the wave fetches anyway and costs less than the cross-lane moves. Default 0.
+#ifndef CP_CURV_SHF
+#define CP_CURV_SHF 0
+#endif
 template <typename S, bool NEUMANN, bool FULLK, int KA = CP_KMAX, int NWV = CP_WAVES>
 __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_curv(MfParams P, const S *__restrict__ xo, S *__restrict__ xn,
                                                                 const S *__restrict__ pin, S *__restrict__ pout,
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_curv(Mf
                 for (int c = 0; c < 2; ++c) {
                     const unsigned so = c ? fsb : 0u;
                     q_w0[c] = bld_raw<S>(r_y2, off, so);
-#if CP_FUSED_SHF
+#if CP_CURV_SHF
                     q_wim[c] = bld_raw<S>(r_y2, (off - ES) | off_l0, so);   // lanes 1..63: out of range, dropped
 #else
                     q_wim[c] = bld_raw<S>(r_y2, off - ES, so);
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_mf_fused_curv(Mf
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const double w0 = (double)q_w0[c];
-#if CP_FUSED_SHF
+#if CP_CURV_SHF
                     const double wsh = lane_shr1<double>(w0);         // evaluated by every lane, before the select
                     const double wim = (lane == 0) ? (double)q_wim[c] : wsh;
 #else
