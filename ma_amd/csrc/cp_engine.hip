@@ -93,6 +93,7 @@ struct cp_engine {
     int nblk = 0;
     int pw_strip = 0;        // columns per wave of k_pw_march (0: k_pw_fused), pw_groups row groups of 63, pw_waves waves
     int pw_groups = 0, pw_waves = 0, pw_grid = 0;
+    bool pw_two = false;     // k_pw_march2: two rows per lane, row groups of 128 aligned rows (m even)
     bool time_all = false;   // CP_TUNE_TIME_ALL=1: HIP events around the small kernels of the fused paths too (each pair of
                              // events costs a few microseconds of stream time; by default only the dominant kernel is timed)
     bool pw_split = false;   // tuning aid (CP_TUNE_PW_SPLIT=1): pairwise models on the split passes instead of k_pw_fused
@@ -474,10 +475,16 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
             // batch, fp64 / fp32 storage): 16 columns 2.04 / 1.03, 8: 1.94 / 0.99, 6: 1.79 / -, 4: 1.81 / 1.08, 3: 1.84, 2: 1.98
             // -- narrow strips recompute more ((C+1)/C evaluations per pixel) but start more waves, and a strip of 8 columns of
             // 512 rows puts the waves 32 KB apart; 2048^2: 4, 6 and 8 alike (0.135), 16: 0.143
-            h->pw_groups = (h->m + 62) / 63;
-            for (int strip : {h->fp32 ? 8 : 6, 4}) {
+            h->pw_two = (h->m % 2 == 0) && h->m >= 128;
+            if (const char *ev = getenv("CP_TUNE_PW_TWO")) h->pw_two = (atoi(ev) != 0) && (h->m % 2 == 0);
+            h->pw_groups = h->pw_two ? (h->m + 127) / 128 : (h->m + 62) / 63;
+            // k_pw_march2 (256 x 512^2): fp64 strips of 4 / 6 / 8 / 12 / 16 / 32 columns 1.64 / 1.617 / 1.70 / 1.69 / 1.73 / 1.68 ms
+            // (k_pw_march with 6: 1.785); fp32 storage 6 / 8 / 16 / 32: 1.10 / 1.07 / 1.02 / 1.01 (k_pw_march with 8: 1.03)
+            const std::vector<int> cands = h->pw_two ? (h->fp32 ? std::vector<int>{32, 16, 8, 4} : std::vector<int>{6, 4})
+                                                     : std::vector<int>{h->fp32 ? 8 : 6, 4};
+            for (int strip : cands) {
                 const long long waves = (long long)h->pw_groups * ((h->nl + strip - 1) / strip) * h->batch;
-                if (waves >= 8192) { h->pw_strip = strip; break; }
+                if (waves >= (h->pw_two ? 4096 : 8192)) { h->pw_strip = strip; break; }   // a wave of k_pw_march2 carries twice the rows
             }
             if (const char *ev = getenv("CP_TUNE_PW_STRIP")) h->pw_strip = std::max(0, atoi(ev));
             if (h->pw_strip > 0) {
@@ -1487,6 +1494,15 @@ static void launch_pw_fused_t(cp_engine *h, const PwParams &P, const double *xo_
     if (h->pw_strip > 0) {
         dim3 mg(h->pw_grid, h->batch);
         const int st = h->pw_strip, ng = h->pw_groups, nw = h->pw_waves;
+        if (h->pw_two) {
+            if (h->gt == GT_SAD_REG)
+                hipLaunchKernelGGL((k_pw_march2<S, GT_SAD_REG>), mg, dim3(CP_BLOCK), 0, h->stream, P, st, ng, nw, xo, xn, vin, vout, g, b, ctrl, h->part);
+            else if (h->gt == GT_SSD_REG)
+                hipLaunchKernelGGL((k_pw_march2<S, GT_SSD_REG>), mg, dim3(CP_BLOCK), 0, h->stream, P, st, ng, nw, xo, xn, vin, vout, g, b, ctrl, h->part);
+            else
+                hipLaunchKernelGGL((k_pw_march2<S, GT_SAD_DEN>), mg, dim3(CP_BLOCK), 0, h->stream, P, st, ng, nw, xo, xn, vin, vout, b, b, ctrl, h->part);
+            return;
+        }
         if (h->gt == GT_SAD_REG)
             hipLaunchKernelGGL((k_pw_march<S, GT_SAD_REG>), mg, dim3(CP_BLOCK), 0, h->stream, P, st, ng, nw, xo, xn, vin, vout, g, b, ctrl, h->part);
         else if (h->gt == GT_SSD_REG)
@@ -1896,7 +1912,7 @@ extern "C" int cp_dominant_kernel(cp_handle h, char *buf, int32_t len) {
         else snprintf(name, sizeof name, "k_var_lazy_tv<%s, %s, %d>", S, tf[h->d.bc == CP_BC_LINEAR && h->var_waves != 8], h->var_waves);
     } else {
         if (h->pw_split) snprintf(name, sizeof name, "k_pw_dual<%s, 0, %d>", S, h->nc);
-        else if (h->pw_strip > 0) snprintf(name, sizeof name, "k_pw_march<%s, %d>", S, h->gt);
+        else if (h->pw_strip > 0) snprintf(name, sizeof name, "%s<%s, %d>", h->pw_two ? "k_pw_march2" : "k_pw_march", S, h->gt);
         else snprintf(name, sizeof name, "k_pw_fused<%s, %d>", S, h->gt);
     }
     snprintf(buf, (size_t)len, "%s", name);

@@ -522,6 +522,195 @@ __global__ __launch_bounds__(CP_BLOCK) void k_pw_march(PwParams P, int strip, in
                                        part + ((size_t)prob * gridDim.x + blockIdx.x) * PWF_PSTRIDE);
 }
 
+// ---- k_pw_march2: the marching form with TWO rows per lane (m even) ----------------------------------------------------------
+// k_pw_march's segments of 63 rows start at multiples of 504 bytes: every wave-wide access straddles five 128-byte lines instead
+// of four, stores write partial lines, and the lines at a segment's ends are fetched by two waves -- config 5 moves 10.6 GB per
+// launch for 8.05 GB of operands. Here a lane owns rows (i, i+1) and a wave 128 ALIGNED rows: every access is one 1 KB run of
+// 16 bytes per lane (8 in fp32 storage). The row above the segment -- its primal value is the (i+1, j) neighbour of the wave's last
+// row and belongs to the wave above -- is evaluated once more from loads at ONE address for the whole wave (a single 64-byte
+// request per field; the evaluation runs in all lanes, the VALU is at 8 % in these kernels): no halo lane, (129/128) (C+1)/C
+// evaluations per pixel. (i-1, j) of a lane's first row is the second row of lane - 1 (cross-lane shift; lane 0 loads it), of
+// its second row its own first.
+template <typename S>
+struct __attribute__((aligned(2 * sizeof(S)))) pw_two { S a, b; };
+template <typename S>
+__device__ __forceinline__ pw_two<S> pw_ld2(const S *p) { return *reinterpret_cast<const pw_two<S> *>(p); }
+template <typename S>
+__device__ __forceinline__ void pw_st2(S *p, double a, double b) { *reinterpret_cast<pw_two<S> *>(p) = pw_two<S>{(S)a, (S)b}; }
+template <int NC>
+struct PwIn2 {
+    PwIn<NC> A, B;          // first / second row of the lane; A.fxm is completed at evaluation time (needs lane - 1's B.fx0)
+    double xm0[NC];         // lane 0: v_x at (i - 1, j) of its first row
+};
+template <typename S, int GT>
+__device__ __forceinline__ void pw_load_two(const PwParams &P, const S *__restrict__ xc, const S *__restrict__ v,
+                                            const S *__restrict__ g, const S *__restrict__ b, int e, int lane,
+                                            PwIn2<(GT == GT_SAD_DEN) ? 1 : 2> &in) {
+    constexpr int NC = (GT == GT_SAD_DEN) ? 1 : 2;
+    const int m = P.m, fs = P.fs;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const S *fx = v + (size_t)(2 * c) * fs + e, *fy = v + (size_t)(2 * c + 1) * fs + e;
+        const pw_two<S> x2 = pw_ld2(fx), y2 = pw_ld2(fy), ym = pw_ld2(fy - m), u2 = pw_ld2(xc + (size_t)c * fs + e);
+        in.xm0[c] = fx[(lane == 0) ? -1 : 0];                  // lanes 1..63: a line the pair load fetches anyway, value unused
+        in.A.fx0[c] = x2.a; in.B.fx0[c] = x2.b; in.B.fxm[c] = x2.a; in.A.fxm[c] = 0.0;
+        in.A.fy0[c] = y2.a; in.B.fy0[c] = y2.b; in.A.fym[c] = ym.a; in.B.fym[c] = ym.b;
+        in.A.u[c] = u2.a; in.B.u[c] = u2.b;
+    }
+    in.A.gx = in.A.gy = in.B.gx = in.B.gy = 0.0;
+    if (GT != GT_SAD_DEN) {
+        const pw_two<S> gx = pw_ld2(g + e), gy = pw_ld2(g + (size_t)fs + e);
+        in.A.gx = gx.a; in.B.gx = gx.b; in.A.gy = gy.a; in.B.gy = gy.b;
+    }
+    const pw_two<S> bb = pw_ld2(b + e);
+    in.A.bb = bb.a; in.B.bb = bb.b;
+}
+template <int NC>
+__device__ __forceinline__ void pw_two_finish(PwIn2<NC> &in, int lane) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double up = __shfl_up(in.B.fx0[c], 1);           // every lane takes part
+        in.A.fxm[c] = (lane == 0) ? in.xm0[c] : up;
+    }
+}
+
+template <typename S, int GT>
+__global__ __launch_bounds__(CP_BLOCK) void k_pw_march2(PwParams P, int strip, int ngroups, int nwaves,
+                                                        const S *__restrict__ xo_, S *__restrict__ xn_,
+                                                        const S *__restrict__ vin_, S *__restrict__ vout_,
+                                                        const S *__restrict__ g_, const S *__restrict__ b_,
+                                                        const PwCtrl *__restrict__ ctrl, double *__restrict__ part) {
+    __shared__ double red[CP_WAVES * PWF_PSTRIDE];
+    constexpr int NC = (GT == GT_SAD_DEN) ? 1 : 2;
+    const int prob = blockIdx.y;
+    if (ctrl[prob].stop) return;
+    const int m = P.m, fs = P.fs;
+    const S *xo = xo_ + (size_t)prob * P.nxf * fs;
+    S *xn = xn_ + (size_t)prob * P.nxf * fs;
+    const S *vin = vin_ + (size_t)prob * P.nvf * fs;
+    S *vout = vout_ + (size_t)prob * P.nvf * fs;
+    const S *g = g_ + (size_t)prob * 2 * fs, *b = b_ + (size_t)prob * fs;
+    const double sigma = P.sigma, theta = P.theta;
+    double sums[PWF_NS] = {0.0, 0.0, 0.0}, maxs[PWF_NM] = {0.0, 0.0};
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * CP_WAVES + (threadIdx.x >> 6);       // wave index: row group fastest, then strip
+    if (w < nwaves) {
+        const int grp = w % ngroups, st = w / ngroups;
+        const int i0 = grp * 128 + 2 * lane;                            // rows i0, i0 + 1 (m even: both exist or neither)
+        const bool own = i0 < m;
+        const int ic = min(i0, m - 2);                                  // rows past the end: clamped address, masked out
+        const bool last_i1 = (ic + 1 == m - 1);                         // of the lane's second row
+        const int ih = min(grp * 128 + 128, m - 1);                     // the row above the segment (clamped: then it is never used)
+        const int j0 = st * strip, j1 = min(j0 + strip, P.n);
+        double unA[2][NC], uoA[2][NC], vA[2][2 * NC], unH[NC], uoH[NC];
+        {
+            PwIn2<NC> t;
+            PwIn<NC> th;
+            const int e = (j0 + 1) * m + ic;
+            pw_load_two<S, GT>(P, xo, vin, g, b, e, lane, t);
+            pw_load_point<S, GT>(P, xo, vin, g, b, (j0 + 1) * m + ih, th);
+            pw_two_finish<NC>(t, lane);
+            double gs[2] = {0.0, 0.0}, gm[1] = {0.0};
+            pw_eval_point<S, 0, GT, true>(P, t.A, ic, j0, unA[0], uoA[0], gs, gm, vA[0]);
+            pw_eval_point<S, 0, GT, true>(P, t.B, ic + 1, j0, unA[1], uoA[1], gs, gm, vA[1]);
+            pw_eval_point<S, 0, GT, false>(P, th, ih, j0, unH, uoH, nullptr, nullptr);
+            if (own) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) pw_st2<S>(xn + (size_t)c * fs + e, unA[0][c], unA[1][c]);
+                sums[1] += gs[0]; sums[2] += gs[1]; maxs[1] = fmax(maxs[1], gm[0]);
+            }
+        }
+        PwIn2<NC> nxt;
+        PwIn<NC> nxth;
+        pw_load_two<S, GT>(P, xo, vin, g, b, (j0 + 2) * m + ic, lane, nxt);
+        pw_load_point<S, GT>(P, xo, vin, g, b, (j0 + 2) * m + ih, nxth);
+        for (int j = j0; j < j1; ++j) {
+            const int e = (j + 1) * m + ic;
+            const bool last_j = (j == P.n - 1);
+            // primal step at column j+1 (the wave's own pixels if the column is inside the strip, else the halo column): its
+            // inputs were loaded one step ago; the loads of column j+2 go out now (clamped to the halo column)
+            PwIn2<NC> cur = nxt;
+            const PwIn<NC> curh = nxth;
+            const int jn = (min(j + 2, P.n) + 1) * m;
+            pw_load_two<S, GT>(P, xo, vin, g, b, jn + ic, lane, nxt);
+            pw_load_point<S, GT>(P, xo, vin, g, b, jn + ih, nxth);
+            pw_two_finish<NC>(cur, lane);
+            double unC[2][NC], uoC[2][NC], vC[2][2 * NC], unHC[NC], uoHC[NC];
+            {
+                double gs[2] = {0.0, 0.0}, gm[1] = {0.0};
+                pw_eval_point<S, 0, GT, true>(P, cur.A, ic, j + 1, unC[0], uoC[0], gs, gm, vC[0]);
+                pw_eval_point<S, 0, GT, true>(P, cur.B, ic + 1, j + 1, unC[1], uoC[1], gs, gm, vC[1]);
+                pw_eval_point<S, 0, GT, false>(P, curh, ih, j + 1, unHC, uoHC, nullptr, nullptr);
+                if (own && j + 1 < j1) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) pw_st2<S>(xn + (size_t)c * fs + e + m, unC[0][c], unC[1][c]);
+                    sums[1] += gs[0]; sums[2] += gs[1]; maxs[1] = fmax(maxs[1], gm[0]);
+                }
+            }
+            double vn[2][2 * NC];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const bool last_i = (r == 1) && last_i1;
+                double dcur[2 * NC], dbar[2 * NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const double u0 = unA[r][c], uold = uoA[r][c];
+                    double ui, uiold;                                                   // (i+1, j)
+                    if (r == 0) { ui = unA[1][c]; uiold = uoA[1][c]; }
+                    else {
+                        const double su = __shfl_down(unA[0][c], 1), so = __shfl_down(uoA[0][c], 1);
+                        ui = (lane == 63) ? unH[c] : su;
+                        uiold = (lane == 63) ? uoH[c] : so;
+                    }
+                    const double ub0 = u0 + theta * (u0 - uold);                           // chambolle_pock.m:179
+                    const double ubi = ui + theta * (ui - uiold);
+                    const double uj = unC[r][c], ubj = uj + theta * (uj - uoC[r][c]);
+                    // neumann rows: PDO/test_TV_L1_registration.m:67-70
+                    dcur[2 * c] = last_i ? 0.0 : (ui - u0) * P.inv_h1;
+                    dcur[2 * c + 1] = last_j ? 0.0 : (uj - u0) * P.inv_h2;
+                    dbar[2 * c] = last_i ? 0.0 : (ubi - ub0) * P.inv_h1;
+                    dbar[2 * c + 1] = last_j ? 0.0 : (ubj - ub0) * P.inv_h2;
+                }
+                double n2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 2 * NC; ++c) n2 += dcur[c] * dcur[c];
+                double nn2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 2 * NC; ++c) {
+                    vn[r][c] = vA[r][c] + sigma * dbar[c];
+                    nn2 += vn[r][c] * vn[r][c];
+                }
+                const double iden = 1.0 / fmax(sqrt(nn2), 1.0);                            // TV_registration.m:68-69
+                nn2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 2 * NC; ++c) {
+                    vn[r][c] = (double)(S)(vn[r][c] * iden);         // the stored (rounded) value is the iterate
+                    nn2 += vn[r][c] * vn[r][c];
+                }
+                if (own) {
+                    sums[0] += sqrt(n2);                                                   // TV_registration.m:38,44
+                    maxs[0] = fmax(maxs[0], sqrt(nn2));                                    // TV_registration.m:60-62
+                }
+            }
+            if (own) {
+#pragma unroll
+                for (int c = 0; c < 2 * NC; ++c) pw_st2<S>(vout + (size_t)c * fs + e, vn[0][c], vn[1][c]);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { unA[r][c] = unC[r][c]; uoA[r][c] = uoC[r][c]; }
+#pragma unroll
+                for (int c = 0; c < 2 * NC; ++c) vA[r][c] = vC[r][c];
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { unH[c] = unHC[c]; uoH[c] = uoHC[c]; }
+        }
+    }
+    block_reduce_store<PWF_NS, PWF_NM>(sums, maxs, red,
+                                       part + ((size_t)prob * gridDim.x + blockIdx.x) * PWF_PSTRIDE);
+}
+
 // history rows of the fused iteration n: primal row n complete, G* part of dual row n (its F* violation was written by
 // the previous launch), F* violation of dual row n+1; then the stop rule on rows n-4..n (chambolle_pock.m:142-153)
 struct PwFusedFinArgs {

@@ -84,9 +84,13 @@ def run_pair_case(t, rng):
     m = int(rng.choice([9, 17, 40, 62, 63, 64, 65, 126, 127, 150]))
     n = int(rng.choice([5, 6, 7, 8, 9, 16, 17, 33, 50, 90]))
     strip = str(rng.choice(["", "4", "6", "8", "16"]))
+    two = str(rng.choice(["", "1"]))          # k_pw_march2 (two rows per lane) forced at even sizes below its default threshold
     os.environ.pop("CP_TUNE_PW_STRIP", None)
+    os.environ.pop("CP_TUNE_PW_TWO", None)
     if strip:
         os.environ["CP_TUNE_PW_STRIP"] = strip
+    if two:
+        os.environ["CP_TUNE_PW_TWO"] = two
     lam, tau = (4.0, 1.5) if term == "SAD" else (50.0, 4.0)
     fr = synth.dynamic_test_image(m, n, 2).numpy()
     if not np.isfinite(fr).all():
@@ -113,6 +117,7 @@ def run_pair_case(t, rng):
     ph, dh = eng.history()
     eng.close()
     os.environ.pop("CP_TUNE_PW_STRIP", None)
+    os.environ.pop("CP_TUNE_PW_TWO", None)
     nr = min(ph.shape[0], phr.shape[0])
     ex, ey = rel(x, xr), rel(y, yr)
     dp = float(np.max(np.abs(ph[:nr] - phr[:nr]) - 1e-9 * np.abs(phr[:nr])))       # atol as tests/test_gpu_pairwise.py

@@ -257,7 +257,7 @@ def test_c5_batch_256_tv_l2_512(fp32, monkeypatch):
     # kernel and strip width, so that the per-problem reduction order -- and with it every bit -- is the batch's
     for p in (0, 100, 255):
         for fl in ((flags,) if not fp32 else (flags, 0)):
-            monkeypatch.setenv("CP_TUNE_PW_STRIP", "8" if (fl & E.FLAG_FP32) else "6")   # cp_create's choice for the batch
+            monkeypatch.setenv("CP_TUNE_PW_STRIP", "32" if (fl & E.FLAG_FP32) else "6")   # cp_create's choice for the batch (k_pw_march2)
             e1 = E.Engine(E.MODEL_TV_L2_REG, m, n, lam=lam, flags=fl)
             e1.set_images(Ts[p], Rv)
             for _ in range(2):

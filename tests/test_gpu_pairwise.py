@@ -201,11 +201,19 @@ def test_batch_matches_single():
         assert np.array_equal(h1[0], hb[0][p]) and np.array_equal(h1[1], hb[1][p])
 
 
-@pytest.mark.parametrize("model,m,n,batch,strip", [("TV_L2", 70, 55, 1, 16), ("TV_L1", 64, 33, 3, 4), ("TV_L2", 130, 20, 2, 7),
-                                                   ("DEN", 63, 17, 1, 16), ("TV_L1", 5, 3, 2, 1), ("DEN", 127, 40, 2, 3)])
-def test_marching_kernel_matches_chunk_kernel_and_split_passes(model, m, n, batch, strip, monkeypatch):
-    """The three implementations of one iteration (split passes, k_pw_fused, k_pw_march with a given strip width) on
-    shapes that are not multiples of the 63-row groups / the strip: same iterates and histories, same stop iteration."""
+@pytest.mark.parametrize("model,m,n,batch,strip,two", [("TV_L2", 70, 55, 1, 16, "0"), ("TV_L1", 64, 33, 3, 4, "0"), ("TV_L2", 130, 20, 2, 7, "0"),
+                                                       ("DEN", 63, 17, 1, 16, ""), ("TV_L1", 5, 3, 2, 1, ""), ("DEN", 127, 40, 2, 3, ""),
+                                                       # k_pw_march2 (two rows per lane, groups of 128 aligned rows): the default from 128
+                                                       # even rows on, forced below: a wave with 35 / 1 / 32 live lanes, a lone pair of rows,
+                                                       # a second group of one lane, exactly two full groups
+                                                       ("TV_L2", 70, 55, 1, 16, "1"), ("TV_L1", 64, 33, 3, 4, "1"), ("TV_L2", 130, 20, 2, 7, ""),
+                                                       ("DEN", 2, 9, 2, 2, "1"), ("TV_L1", 256, 11, 1, 5, ""), ("DEN", 258, 6, 2, 32, "")])
+def test_marching_kernel_matches_chunk_kernel_and_split_passes(model, m, n, batch, strip, two, monkeypatch):
+    """The three implementations of one iteration (split passes, k_pw_fused, k_pw_march / k_pw_march2 with a given strip width)
+    on shapes that are not multiples of the row groups / the strip: same iterates and histories, same stop iteration."""
+    monkeypatch.delenv("CP_TUNE_PW_TWO", raising=False)
+    if two:
+        monkeypatch.setenv("CP_TUNE_PW_TWO", two)
     from ma_amd import engine as E, synth
     from ma_amd.drivers import normalize
     rng = np.random.default_rng(7)
@@ -239,6 +247,9 @@ def test_marching_kernel_matches_chunk_kernel_and_split_passes(model, m, n, batc
         its = [eng.result(p).iterations for p in range(batch)]
         ph, dh = eng.history()
         out[tag] = (eng.primal(), eng.dual(), ph if batch > 1 else [ph], dh if batch > 1 else [dh], its)
+        if tag == "march":
+            want = "k_pw_march2<" if (m % 2 == 0 and (two == "1" or (two == "" and m >= 128))) else "k_pw_march<"
+            assert eng.dominant_kernel().startswith(want), eng.dominant_kernel()
         eng.close()
     ref = out["split"]
     for tag in ("chunk", "march"):
