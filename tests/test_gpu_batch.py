@@ -4,6 +4,7 @@ import subprocess
 import sys
 
 import pytest
+from conftest import run_command
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +15,7 @@ def test_batch_shards_match_single_handle(world, P, fp32):
     env = dict(os.environ, BATCH_P=str(P), BATCH_FP32=fp32, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29440 + world), os.path.join(ROOT, "tests", "batch_worker.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
+    r = run_command(cmd, env=env, timeout=200)
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0 and "batch shards == single handle" in r.stdout
 
@@ -25,7 +26,7 @@ def test_multi_image_batch_shards_match_the_drivers():
     env = dict(os.environ, BATCH_P="2", BATCH_FP32="0", BATCH_MULTI="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", "29446", os.path.join(ROOT, "tests", "batch_worker.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    r = run_command(cmd, env=env, timeout=280)
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0 and "multi-image batch == drivers one by one" in r.stdout
 
@@ -37,7 +38,7 @@ def test_bench_batch_workload_two_ranks():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29447", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "batch", "--size", "96",
            "--problems", "9", "--steps", "6", "--warmup", "2"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=250)
+    r = run_command(cmd, env=env, timeout=250)
     print(r.stdout[-1500:], r.stderr[-1500:])
     assert r.returncode == 0
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

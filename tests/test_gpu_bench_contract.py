@@ -6,14 +6,14 @@ import subprocess
 import sys
 
 import pytest
+from conftest import run_command
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=250,
-                       env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    r = run_command([sys.executable, os.path.join(ROOT, "bench.py")] + args, timeout=250, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     print(r.stdout[-1500:], r.stderr[-1500:])
     assert r.returncode == 0
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -65,8 +65,8 @@ def test_bench_self_launch_without_a_launcher():
     (CP_BENCH_BACKEND=gloo: messages staged through the host)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(CP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "256", "--k", "4", "--steps", "4",
-                        "--warmup", "2", "--repeats", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=250, env=env)
+    r = run_command([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "256", "--k", "4", "--steps", "4",
+                     "--warmup", "2", "--repeats", "2", "--no-cpu-baseline"], timeout=250, env=env)
     print(r.stdout[-1500:], r.stderr[-1500:])
     assert r.returncode == 0
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

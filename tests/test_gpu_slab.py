@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import pytest
+from conftest import run_command
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +17,7 @@ def test_slabs_match_single_gpu(world, k, reg, bc):
     env = dict(os.environ, SLAB_K=str(k), SLAB_REG=reg, SLAB_BC=bc, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29400 + world), os.path.join(ROOT, "tests", "slab_worker.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
+    r = run_command(cmd, env=env, timeout=200)
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0
 
@@ -29,7 +30,7 @@ def test_slabs_with_the_wave_hand_over_kernel(world):
     env = dict(os.environ, SLAB_K="16", SLAB_REG="tv", SLAB_BC="neumann", MASTER_ADDR="127.0.0.1", CP_TUNE_FUSED_WAVES="8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29440 + world), os.path.join(ROOT, "tests", "slab_worker.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
+    r = run_command(cmd, env=env, timeout=200)
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0
 
@@ -40,7 +41,7 @@ def test_rccl_backend_single_rank():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", "29431", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--size", "512", "--k", "16",
            "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=250)
+    r = run_command(cmd, env=env, timeout=250)
     print(r.stdout[-1500:], r.stderr[-1500:])
     assert r.returncode == 0 and '"metric"' in r.stdout
 
@@ -54,7 +55,7 @@ def test_bench_row_slabs_multi_rank(world, reg):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(29450 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size",
            "192", "--k", "6", "--reg", reg, "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=250)
+    r = run_command(cmd, env=env, timeout=250)
     print(r.stdout[-1500:], r.stderr[-1500:])
     assert r.returncode == 0
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -68,7 +69,7 @@ def _run_worker(world, port, **env_extra):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", **{k: str(v) for k, v in env_extra.items()})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    r = run_command(cmd, env=env, timeout=300)
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0
 
