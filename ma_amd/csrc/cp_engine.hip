@@ -106,6 +106,7 @@ struct cp_engine {
     int fused_ka = 1;    // use the K <= 4 / 8 / 12 instantiations of k_mf_fused_tv (CP_TUNE_FUSED_KA=0: always 16)
     int nblk_fused = 0;  // grid of k_mf_fused_tv / k_mf_fused_curv (2 workgroups per CU resident: two LDS tiles per wave)
     int nblk_y2 = 0;     // grid of k_curv_y2
+    int nblk_pow = 0;    // grid of the power iteration's kernels (cp_norm_estimate)
     bool y2_r2 = false;  // k_curv_y2_r2 (two rows per lane; m even)
     int curv_waves = CP_WAVES, nblk_curv = 0;   // wavefronts (adjacent columns) per workgroup of k_mf_fused_curv and its grid (CP_TUNE_CURV_WAVES = 4 | 8)
     bool curv_fused = false;   // NN-curvature on k_mf_fused_curv + k_curv_y2 (CP_TUNE_CURV_SPLIT=1: the split passes)
@@ -385,6 +386,9 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         if (!mf && h->gt != GT_SAD_DEN) HIPCHK(hipMalloc(&h->imgR, sizeof(double) * imgN));
         h->nblk = grid_for(h);
         if (h->km == CP_KBIG) h->nblk = std::min(h->nblk, 256);   // k_big_* reduce the partial rows without a first stage
+        // measured at 4096^2 x 16 (NN-curvature, ms per power step): 768 blocks 13.1, 2048 11.6, 4096 9.7, 8192 9.4; 1024^2 x 16: 0.75 / 0.67 / 0.68
+        h->nblk_pow = std::max(h->nblk, std::min((h->npix + CP_BLOCK - 1) / CP_BLOCK, CP_FUSED_MAXGRID));
+        if (const char *ev = getenv("CP_TUNE_POW_GRID")) h->nblk_pow = std::max(1, atoi(ev));
         // k_mf_fused_tv: one workgroup task per (part of a column, group of 4 columns), up to 4096 workgroups (512 are
         // resident: 2 per CU), tasks strided by the grid; a multiple of 8 workgroups keeps a part on one XCD. Measured at
         // 4096^2 x 16: 10.4-10.7 ms for grids of 4096, 2048, 1024; 10.8 ms for 512 (persistent).
@@ -455,7 +459,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
                     HIPCHK(hipMalloc(&h->vlazy[a], sizeof(double) * 2 * (size_t)h->fs));
                     HIPCHK(hipMemsetAsync(h->vlazy[a], 0, sizeof(double) * 2 * (size_t)h->fs, h->stream));
                 }
-            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(std::max(std::max(h->nblk, h->nblk_fused), h->nblk_tv), h->nblk_y2) *
+            HIPCHK(hipMalloc(&h->part, sizeof(double) * (size_t)std::max(std::max(std::max(std::max(h->nblk, h->nblk_fused), h->nblk_tv), h->nblk_y2), h->nblk_pow) *
                                            (h->km == CP_KBIG ? cp_pstride<CP_KBIG>() : CP_PSTRIDE)));
             HIPCHK(hipMalloc(&h->part2, sizeof(double) * (size_t)(CP_FUSED_MAXGRID / CP_S1_GROUP) * CP_PSTRIDE));
             HIPCHK(hipMalloc(&h->svout, sizeof(double) * (h->km + 2 * h->km * h->km)));
@@ -661,39 +665,41 @@ static void launch_gram_field(cp_engine *h, const MfParams &P, const double *fie
 }
 // y = A*(scale*x) and xo = A'*y of the power iteration; its vectors are doubles in every mode (the spare buffers
 // are double-sized), only the gradient field follows the storage mode
-static void launch_mf_applyA(cp_engine *h, const MfParams &P, const double *x, double scale, double *y) {
+static void launch_mf_applyA(cp_engine *h, const MfParams &P, const double *x, double scale, double *y, int grid) {
     if (h->fp32) {
-        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyA<float, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
-        else hipLaunchKernelGGL((k_mf_applyA<float, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
+        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyA<float, 0>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
+        else hipLaunchKernelGGL((k_mf_applyA<float, 1>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
     } else {
-        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyA<double, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
-        else hipLaunchKernelGGL((k_mf_applyA<double, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
+        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyA<double, 0>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
+        else hipLaunchKernelGGL((k_mf_applyA<double, 1>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
     }
 }
-static void launch_mf_applyAT(cp_engine *h, const MfParams &P, const double *y, double *xo) {
+static void launch_mf_applyAT(cp_engine *h, const MfParams &P, const double *y, double *xo, int grid) {
     if (h->fp32) {
-        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyAT<float, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
-        else hipLaunchKernelGGL((k_mf_applyAT<float, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
+        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyAT<float, 0>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
+        else hipLaunchKernelGGL((k_mf_applyAT<float, 1>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
     } else {
-        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyAT<double, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
-        else hipLaunchKernelGGL((k_mf_applyAT<double, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
+        if (h->reg == 0) hipLaunchKernelGGL((k_mf_applyAT<double, 0>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
+        else hipLaunchKernelGGL((k_mf_applyAT<double, 1>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
     }
 }
-static void launch_any_applyA(cp_engine *h, const MfParams &P, const double *x, double scale, double *y) {
+static void launch_any_applyA(cp_engine *h, const MfParams &P, const double *x, double scale, double *y, int grid = 0) {
+    if (grid <= 0) grid = h->nblk;
     if (h->var && h->fp32) {
-        if (h->reg == 0) hipLaunchKernelGGL((k_var_applyA<float, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
-        else hipLaunchKernelGGL((k_var_applyA<float, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
-    } else if (h->var && h->reg == 0) hipLaunchKernelGGL((k_var_applyA<double, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
-    else if (h->var) hipLaunchKernelGGL((k_var_applyA<double, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
-    else launch_mf_applyA(h, P, x, scale, y);
+        if (h->reg == 0) hipLaunchKernelGGL((k_var_applyA<float, 0>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
+        else hipLaunchKernelGGL((k_var_applyA<float, 1>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, x, scale, (const float *)h->g, y);
+    } else if (h->var && h->reg == 0) hipLaunchKernelGGL((k_var_applyA<double, 0>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
+    else if (h->var) hipLaunchKernelGGL((k_var_applyA<double, 1>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, x, scale, h->g, y);
+    else launch_mf_applyA(h, P, x, scale, y, grid);
 }
-static void launch_any_applyAT(cp_engine *h, const MfParams &P, const double *y, double *xo) {
+static void launch_any_applyAT(cp_engine *h, const MfParams &P, const double *y, double *xo, int grid = 0) {
+    if (grid <= 0) grid = h->nblk;
     if (h->var && h->fp32) {
-        if (h->reg == 0) hipLaunchKernelGGL((k_var_applyAT<float, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
-        else hipLaunchKernelGGL((k_var_applyAT<float, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
-    } else if (h->var && h->reg == 0) hipLaunchKernelGGL((k_var_applyAT<double, 0>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
-    else if (h->var) hipLaunchKernelGGL((k_var_applyAT<double, 1>), dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
-    else launch_mf_applyAT(h, P, y, xo);
+        if (h->reg == 0) hipLaunchKernelGGL((k_var_applyAT<float, 0>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
+        else hipLaunchKernelGGL((k_var_applyAT<float, 1>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, y, (const float *)h->g, xo, h->part);
+    } else if (h->var && h->reg == 0) hipLaunchKernelGGL((k_var_applyAT<double, 0>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
+    else if (h->var) hipLaunchKernelGGL((k_var_applyAT<double, 1>), dim3(grid), dim3(CP_BLOCK), 0, h->stream, P, y, h->g, xo, h->part);
+    else launch_mf_applyAT(h, P, y, xo, grid);
 }
 // the power iteration's vectors move between host and device as doubles in every mode
 struct Fp64Transfers {
@@ -758,6 +764,20 @@ __global__ __launch_bounds__(CP_BLOCK) void k_sumsq_fields(int npix, int m, int 
     block_reduce_store<1, 1>(ss, mm, red, part + (size_t)blockIdx.x * CP_PSTRIDE);
 }
 
+// sum of the first entry of `rows` partial rows (fixed order: thread t takes rows t, t + 256, ...; then a tree over the 256 threads)
+__global__ __launch_bounds__(256) void k_pow_rowsum(const double *__restrict__ part, int rows, int stride, double *__restrict__ out) {
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) a += part[(size_t)r * stride];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
 extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int32_t *iters) {
     if (!h || !h->mf || !est) CP_FAIL(CP_ERR_BAD_ARG, "cpengine:badArg cp_norm_estimate needs an mf_nn handle");
     HIPCHK(hipSetDevice(h->d.device));
@@ -770,14 +790,14 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
     HIPCHK(hipMemsetAsync(xb, 0, sizeof(double) * h->xN, h->stream));
     if (x0) { Fp64Transfers t(h); CPCHK(upload_fields(h, xa, x0, h->nxf)); }
     else hipLaunchKernelGGL(k_mf_hash_start, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, P, h->nxf, xa);
-    // ||x0||
-    std::vector<double> hp((size_t)h->nblk * CP_PSTRIDE);
-    auto sumsq_partials = [&](double &out) -> int {
-        HIPCHK(hipMemcpyAsync(hp.data(), h->part, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, h->stream));
+    // ||x0||. Round 3: the partial sums of a step are added on the device (k_pow_rowsum) and ONE double comes back to the host; before,
+    // whole partial rows (768 x 532 doubles through pageable memory) came back every step, half of a step's 26 ms at 4096^2 x 16.
+    // The two kernels of a step have no LDS tiles, so their grid may exceed that of the field passes (CP_TUNE_POW_GRID).
+    const int pgrid = h->nblk_pow;
+    auto sumsq_partials = [&](int rows, double &out) -> int {
+        hipLaunchKernelGGL(k_pow_rowsum, dim3(1), dim3(256), 0, h->stream, (const double *)h->part, rows, (int)CP_PSTRIDE, h->red);
+        HIPCHK(hipMemcpyAsync(&out, h->red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        double s = 0.0;
-        for (int bI = 0; bI < h->nblk; ++bI) s += hp[(size_t)bI * CP_PSTRIDE];
-        out = s;
         return CP_OK;
     };
     double nrm2 = 0.0;
@@ -785,7 +805,7 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
     // per call at 4096^2 x 16 (6.4 GB through pageable memory)
     hipLaunchKernelGGL(k_sumsq_fields, dim3(h->nblk), dim3(CP_BLOCK), 0, h->stream, h->npix, h->m, h->fs, h->nxf, xa, h->part);
     HIPCHK(hipGetLastError());
-    CPCHK(sumsq_partials(nrm2));
+    CPCHK(sumsq_partials(h->nblk, nrm2));
     double scale = 1.0 / std::sqrt(nrm2);                       // NNE/matrix_norm.m:23
     const double tol = 1e-6;
     const int maxIter = 100;
@@ -793,11 +813,11 @@ extern "C" int cp_norm_estimate(cp_handle h, const double *x0, double *est, int3
     int i = 0;
     while (i < 2 || std::fabs(e[i - 1] - e[i - 2]) > tol * e[i - 1]) {   // :25
         ++i;
-        launch_any_applyA(h, P, xa, scale, yb);
-        launch_any_applyAT(h, P, yb, xb);
+        launch_any_applyA(h, P, xa, scale, yb, pgrid);
+        launch_any_applyAT(h, P, yb, xb, pgrid);
         HIPCHK(hipGetLastError());
         double ss;
-        CPCHK(sumsq_partials(ss));
+        CPCHK(sumsq_partials(pgrid, ss));
         const double normY = std::sqrt(ss);                     // :35
         scale = 1.0 / normY;                                    // :38
         std::swap(xa, xb);
@@ -2239,10 +2259,10 @@ extern "C" int cp_mg_stage(cp_handle h, int stage, int32_t n, double *dev_buf, i
             break;
         }
         case CP_STAGE_APPLY_A:
-            launch_mf_applyA(h, P, h->X[1], scale, h->P[1]);
+            launch_mf_applyA(h, P, h->X[1], scale, h->P[1], h->nblk);
             break;
         case CP_STAGE_APPLY_AT:
-            launch_mf_applyAT(h, P, h->P[1], h->xtmp);
+            launch_mf_applyAT(h, P, h->P[1], h->xtmp, h->nblk);
             {
                 int nrows_l = 0;
                 const double *rows_l = staged_partials(h, h->nblk, &nrows_l);
