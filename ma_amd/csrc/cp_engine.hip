@@ -123,6 +123,8 @@ struct cp_engine {
 };
 
 // ------------------------------------------------------------------------------------------------
+static const double *staged_partials(cp_engine *h, int nrows, int *rows, bool scalars_only = false);   // below, with the reductions
+
 static MfParams mf_params(const cp_engine *h, double theta, double tau, double sigma) {
     MfParams P;
     P.m = h->m; P.nl = h->nl; P.K = h->K; P.npix = h->npix;
@@ -385,7 +387,7 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         HIPCHK(hipMalloc(&h->img, sizeof(double) * imgN));
         if (!mf && h->gt != GT_SAD_DEN) HIPCHK(hipMalloc(&h->imgR, sizeof(double) * imgN));
         h->nblk = grid_for(h);
-        if (h->km == CP_KBIG) h->nblk = std::min(h->nblk, 256);   // k_big_* reduce the partial rows without a first stage
+        if (const char *ev = getenv("CP_TUNE_BIG_GRID")) { if (h->km == CP_KBIG) h->nblk = std::max(1, std::min(h->nblk, atoi(ev))); }
         // measured at 4096^2 x 16 (NN-curvature, ms per power step): 768 blocks 13.1, 2048 11.6, 4096 9.7, 8192 9.4; 1024^2 x 16: 0.75 / 0.67 / 0.68
         h->nblk_pow = std::max(h->nblk, std::min((h->npix + CP_BLOCK - 1) / CP_BLOCK, CP_FUSED_MAXGRID));
         if (const char *ev = getenv("CP_TUNE_POW_GRID")) h->nblk_pow = std::max(1, atoi(ev));
@@ -729,7 +731,11 @@ extern "C" int cp_singular_values(cp_handle h, int which, double *sv) {
     const int km = h->km;
     double *ident = h->svout + km + km * km, *vout = h->svout + km;
     auto sv_eig = [&](const double *Vin) {
-        if (km == CP_KBIG) hipLaunchKernelGGL(k_big_sv_eig, dim3(1), dim3(CP_BIG_THREADS), 0, h->stream, h->nblk, h->part, Vin, h->svout);
+        if (km == CP_KBIG) {
+            int nr = 0;
+            const double *rows = staged_partials(h, h->nblk, &nr);   // only the Gram block of the rows is meaningful here
+            hipLaunchKernelGGL(k_big_sv_eig, dim3(1), dim3(CP_BIG_THREADS), 0, h->stream, nr, rows, Vin, h->svout);
+        }
         else hipLaunchKernelGGL(k_mf_sv_eig, dim3(1), dim3(CP_BLOCK), 0, h->stream, h->nblk, h->part, Vin, h->svout);
     };
     launch_gram_field(h, P, field, ident);
@@ -978,10 +984,40 @@ __global__ __launch_bounds__(1024) void k_mf_reduce_stage1(int nrows, const doub
     }
 }
 
+// the same for the partial rows of the KM = 32 field kernels (cp_pstride<32>() doubles per row): groups of 32 rows, fixed order
+__global__ __launch_bounds__(256) void k_big_reduce_stage1(int nrows, const double *__restrict__ part, double *__restrict__ out) {
+    constexpr int PS = cp_pstride<CP_KBIG>();
+    const int col = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (col >= PS) return;
+    const bool is_max = (col >= CP_NSUM && col < CP_NSCAL);
+    const int r1 = min(nrows, g * 32 + 32);
+    double v[4] = {is_max ? -1.0e300 : 0.0, is_max ? -1.0e300 : 0.0, is_max ? -1.0e300 : 0.0, is_max ? -1.0e300 : 0.0};
+    int r = g * 32;
+    for (; r + 3 < r1; r += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double o = part[(size_t)(r + u) * PS + col];
+            v[u] = is_max ? fmax(v[u], o) : v[u] + o;
+        }
+    }
+    for (int u = 0; r < r1; ++r, ++u) {
+        const double o = part[(size_t)r * PS + col];
+        v[u] = is_max ? fmax(v[u], o) : v[u] + o;
+    }
+    out[(size_t)g * PS + col] = is_max ? fmax(fmax(v[0], v[1]), fmax(v[2], v[3])) : (v[0] + v[1]) + (v[2] + v[3]);
+}
+
 // partial rows of the last field kernel as the single-workgroup kernels read them (after stage 1 if there are more than
 // 128: a single workgroup reads about 18 rows per microsecond)
-static const double *staged_partials(cp_engine *h, int nrows, int *rows, bool scalars_only = false) {
-    if (nrows <= 128 || h->km == CP_KBIG) { *rows = nrows; return h->part; }   // K > 16: rows of cp_pstride<32>, at most 256 of them
+static const double *staged_partials(cp_engine *h, int nrows, int *rows, bool scalars_only) {
+    if (h->km == CP_KBIG) {   // K > 16: rows of cp_pstride<32>() doubles; one workgroup reads 16.5 KB per row (0.2 ms for 256 rows)
+        if (nrows <= 32) { *rows = nrows; return h->part; }
+        const int r2 = (nrows + 31) / 32;
+        hipLaunchKernelGGL(k_big_reduce_stage1, dim3((cp_pstride<CP_KBIG>() + 255) / 256, r2), dim3(256), 0, h->stream, nrows, h->part, h->part2);
+        *rows = r2;
+        return h->part2;
+    }
+    if (nrows <= 128) { *rows = nrows; return h->part; }
     const int r2 = (nrows + CP_S1_GROUP - 1) / CP_S1_GROUP;
     hipLaunchKernelGGL(k_mf_reduce_stage1, dim3(r2, scalars_only ? 1 : (CP_PSTRIDE + 255) / 256), dim3(1024), 0, h->stream, nrows, h->part,
                        h->part2);

@@ -43,8 +43,10 @@ __device__ __forceinline__ void big_reduce(const double *__restrict__ part, int 
 // Cyclic Jacobi on a symmetric 32 x 32 matrix in LDS, 1024 threads, round-robin ordering: 31 rounds of 16 disjoint
 // rotations per sweep (jacobi16 of cp_mfnn_small.cuh with N = 32). On exit diag(G) holds the eigenvalues and the columns
 // of V the eigenvectors: G_in = V diag V'. V must hold the identity (or the basis to be rotated) on entry.
-__device__ void big_jacobi(BigMat G, BigMat V, double (*cs)[2], int (*pq)[2], int *rotflag) {
-    constexpr int N = CP_KBIG;
+// Kp: the tournament runs over the even number Kp >= K of players -- rows and columns K..31 of a zero-padded Gram matrix are zero,
+// rotations against them are identities (as the 16 x 16 kernels do): K = 20 plays 19 rounds per sweep instead of 31.
+__device__ void big_jacobi(BigMat G, BigMat V, double (*cs)[2], int (*pq)[2], int *rotflag, int Kp = CP_KBIG) {
+    const int N = Kp;
     const int t = threadIdx.x, r_ = t >> 5, c_ = t & 31;
     {
         const double s = 0.5 * (G[r_][c_] + G[c_][r_]);
@@ -67,7 +69,7 @@ __device__ void big_jacobi(BigMat G, BigMat V, double (*cs)[2], int (*pq)[2], in
                 cs[t][0] = c; cs[t][1] = s; pq[t][0] = p; pq[t][1] = q;
             }
             __syncthreads();
-            {   // columns: G <- G J (threads 0..511), V <- V J (threads 512..1023)
+            if (((t >> 5) & 15) < N / 2) {   // columns: G <- G J (threads 0..511), V <- V J (threads 512..1023)
                 const int pi = (t >> 5) & 15, l = t & 31;
                 const int p = pq[pi][0], q = pq[pi][1];
                 const double c = cs[pi][0], s = cs[pi][1];
@@ -77,7 +79,7 @@ __device__ void big_jacobi(BigMat G, BigMat V, double (*cs)[2], int (*pq)[2], in
                 M[l][q] = s * mp + c * mq;
             }
             __syncthreads();
-            if (t < 512) {   // rows: G <- J' G
+            if (t < 512 && (t >> 5) < N / 2) {   // rows: G <- J' G
                 const int pi = t >> 5, l = t & 31;
                 const int p = pq[pi][0], q = pq[pi][1];
                 const double c = cs[pi][0], s = cs[pi][1];
@@ -96,7 +98,7 @@ __device__ void big_jacobi(BigMat G, BigMat V, double (*cs)[2], int (*pq)[2], in
 // eigen-decomposition with the warm start of eig16_warm: G' = V0' G V0 with the previous eigenvectors is almost diagonal;
 // eigenvectors in the original basis V0 * V, stored back to vwarm (1024 doubles) for the next call. Ends with a barrier.
 __device__ void big_eig_warm(BigMat G, BigMat V, BigMat V0, BigMat Tm, double (*cs)[2], int (*pq)[2], int *rotflag,
-                             double *__restrict__ vwarm, int warm) {
+                             double *__restrict__ vwarm, int warm, int Kp = CP_KBIG) {
     constexpr int N = CP_KBIG;
     const int t = threadIdx.x, r = t >> 5, c = t & 31;
     const bool w = warm && vwarm;
@@ -114,7 +116,7 @@ __device__ void big_eig_warm(BigMat G, BigMat V, BigMat V0, BigMat Tm, double (*
         G[r][c] = acc;
     }
     __syncthreads();
-    big_jacobi(G, V, cs, pq, rotflag);
+    big_jacobi(G, V, cs, pq, rotflag, Kp);
     if (w) {
         double acc = 0.0;
         for (int i = 0; i < N; ++i) acc += V0[r][i] * V[i][c];
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(CP_BIG_THREADS) void k_big_eig(EigArgs A, const dou
     const double nu = ctrl->nu;
     big_reduce(part, A.nblk, Gs, sc);
     if (stopped) return;
-    big_eig_warm(Gs, Vs, V0s, Tms, cs, pq, &rotflag, A.vwarm, A.warm);
+    big_eig_warm(Gs, Vs, V0s, Tms, cs, pq, &rotflag, A.vwarm, A.warm, (A.K + 1) & ~1);
     if (t == 0) big_l1ball_scale(Gs, A.K, nu * A.sigma, dvec, res, ctrl->sv);   // NNE/nuclear_norm_constraint.m:72
     __syncthreads();
     if (t == 0) {
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(CP_BIG_THREADS) void k_big_fin(EigArgs A, const dou
         Gs[a_][b_] = acc;
         __syncthreads();
     }
-    big_eig_warm(Gs, Vs, V0s, Tms, cs, pq, &rotflag, A.vwarm, A.warm);
+    big_eig_warm(Gs, Vs, V0s, Tms, cs, pq, &rotflag, A.vwarm, A.warm, (A.K + 1) & ~1);
     if (t == 0) {
         double sumS = 0.0;
         for (int i = 0; i < A.K; ++i) ctrl->svL[i] = 0.0;
