@@ -402,19 +402,36 @@ extern "C" int cp_create(const cp_problem_desc *desc, cp_handle *out) {
         h->fused_waves = 8;
         bool force8 = false;   // CP_TUNE_FUSED_WAVES=8: also for small problems and fp32 storage (tests of the hand-over at small sizes)
         if (const char *ev = getenv("CP_TUNE_FUSED_WAVES")) { if (atoi(ev) == 4) h->fused_waves = CP_WAVES; force8 = atoi(ev) == 8; }
-        if (!(mf && !var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (h->d.flags & CP_FLAG_MFNN_NORM21) || h->fused_cw != 1 ||
-            h->K <= 4 || (!force8 && (fused2_tasks(h->m, h->nl, 1, 8) < 256 || fused2_geom(h->m, 64).steps < 8 || (h->d.flags & CP_FLAG_FP32))))
-            // fp32 storage: 5.5 vs 6.9 ms with 4 waves. Fewer than 8 steps per task (m < 3585): the staircase start of the
-            // hand-over is not amortised -- 2048^2 x 16: 2.58 vs 2.55 ms, 1024^2: 0.68 vs 0.66; 4096 x 512 (a slab): 1.37 vs 1.41
-            // in favour of 8 waves. K = 5..15 (KA = 8, 12, 16 instantiations): 4096^2 x 12 7.39 vs 7.47 ms, x 8 4.83 vs 4.93
-            h->fused_waves = CP_WAVES;
         if (const char *ev = getenv("CP_TUNE_PARTS8")) h->parts8 = std::max(0, atoi(ev));
+        if (h->parts8 == 0 && mf) {
+            // parts per column of the hand-over kernels: the fewest (longest tasks) for which the tasks fill whole rounds of the 256 CUs
+            // to >= 95 % -- 1536^2 x 16: 2 parts (384 tasks, 1.5 rounds) 1.51 ms, 4 parts (768 tasks) 1.31, the 4-wave kernel 1.39;
+            // if no count does (768^2: 288 / 384 / 576 tasks), fused2_cap's rule stays and handover_fits() below turns the kernel down
+            const int cg8 = (h->nl + 7) / 8;
+            for (int pc = 2; pc <= CP_FUSED_PARTS; ++pc) {
+                const long long t = (long long)fused2_geom(h->m, 64, pc).parts * cg8;
+                if (t >= 256 && t * 20 >= (t + 255) / 256 * 256 * 19) { h->parts8 = pc; break; }
+            }
+        }
+        // Round 3: with the boundary array, the compiler-only hand-over fences and the field stagger the hand-over kernels win wherever
+        // their tasks load the 256 CUs evenly (one workgroup per CU): 2048^2 x 16 2.38 -> 2.22 ms, 1024^2 x 16 0.634 -> 0.564, 1024^2 x 10
+        // 0.422 -> 0.365, 512^2 x 16 0.181 -> 0.157 (var-TV 2.04 -> 1.78, 0.559 -> 0.475, 0.160 -> 0.134); with 1.5 rounds of tasks they
+        // lose: 1536^2 1.39 -> 1.51 (384 tasks), 768^2 0.409 -> 0.423, 384^2 0.138 -> 0.156, and 256^2 (128 tasks) 0.064 -> 0.081.
+        // Round 2's rule asked for >= 8 segments per task (m >= 3585).
+        auto handover_fits = [&]() {
+            const long long t = fused2_tasks(h->m, h->nl, 1, 8, h->parts8);
+            return t >= 256 && t * 20 >= (t + 255) / 256 * 256 * 19;   // every CU a task, and the last round at least 95 % full
+        };
+        if (!(mf && !var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (h->d.flags & CP_FLAG_MFNN_NORM21) || h->fused_cw != 1 ||
+            h->K <= 4 || (!force8 && (!handover_fits() || (h->d.flags & CP_FLAG_FP32))))
+            // fp32 storage: 5.5 vs 6.9 ms with 4 waves. K = 5..15 (KA = 8, 12, 16 instantiations): 4096^2 x 12 7.39 vs 7.47 ms, x 8 4.83 vs 4.93
+            h->fused_waves = CP_WAVES;
         h->nblk_tv = (int)std::min<long long>((fused2_tasks(h->m, h->nl, h->fused_cw, h->fused_waves, h->parts8) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         {
             h->var_waves = 8;
             bool force8v = false;
             if (const char *ev = getenv("CP_TUNE_VAR_WAVES")) { if (atoi(ev) == 4) h->var_waves = CP_WAVES; force8v = atoi(ev) == 8; }
-            if (!(var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (!force8v && (fused2_tasks(h->m, h->nl, 1, 8) < 256 || fused2_geom(h->m, 64).steps < 8 || h->fp32))) h->var_waves = CP_WAVES;
+            if (!(var && h->reg == 0) || h->d.bc == CP_BC_LINEAR || (!force8v && (!handover_fits() || h->fp32))) h->var_waves = CP_WAVES;
             h->nblk_var = (int)std::min<long long>((fused2_tasks(h->m, h->nl, 1, h->var_waves, h->parts8) + 7) / 8 * 8, CP_FUSED_MAXGRID);
         }
         h->curv_fused = mf && !var && h->reg == 1;

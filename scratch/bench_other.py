@@ -40,7 +40,7 @@ if "c5" in which:
         tau = 4.0; run(f"C5 TV-L2 256 x 512^2 {tag}", eng, 1.0, tau, (1 - 1e-4) / (8 * tau), 100, 23 * esz * m * n * B); eng.close()
 for tag, model, el, mu in (("c4", E.MODEL_MF_NN_CURV, 31, 20.0), ("var", E.MODEL_VAR_TV, 28, 0.1), ("varc", E.MODEL_VAR_CURV, 22, 5.0)):
     if tag not in which: continue
-    m = n = 4096; k = 16
+    m = n = int(os.environ.get("BENCH_SIZE", "4096")); k = int(os.environ.get("BENCH_K", "16"))
     dev = torch.device("cuda", 0)
     imgs = synth.dynamic_test_image(m, n, k, device=dev).transpose(1, 2).contiguous().cpu().numpy().reshape(-1)
     u0 = synth.smooth_displacement(m, n, k, amp=2.0, device=dev).cpu().numpy().reshape(-1)
@@ -50,7 +50,7 @@ for tag, model, el, mu in (("c4", E.MODEL_MF_NN_CURV, 31, 20.0), ("var", E.MODEL
     eng.set_images(imgs)
     eng.set_primal(np.concatenate([u0, np.zeros(k*m*n)]) if tag == "c4" else u0); eng.linearize()
     if tag == "c4": eng.set_nu(30.0)
-    run({"c4": "C4 NN-curvature", "var": "var-TV", "varc": "var-curvature"}[tag] + " 4096^2 x 16" + (" fp32 storage" if fl32 else ""), eng, 1.0, 0.1, 0.1, 20, el * (4.0 if fl32 else 8.0) * k * m * n); eng.close()
+    run({"c4": "C4 NN-curvature", "var": "var-TV", "varc": "var-curvature"}[tag] + f" {m}^2 x {k}" + (" fp32 storage" if fl32 else ""), eng, 1.0, 0.1, 0.1, 20, el * (4.0 if fl32 else 8.0) * k * m * n); eng.close()
 if "c1" in which:
     # C1: TV-L1 denoising of Data/rect1.png (fixture copy) with the committed salt & pepper mask, PDO/test_TV_L1_denoising.m
     from ma_amd import drivers as D
