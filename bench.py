@@ -339,6 +339,10 @@ def main_batch(args):
 
 def main():
     args = parse()
+    # this pool's host driver only supports dmabuf IPC: without the variable RCCL between processes fails with
+    # "hipIpcGetMemHandle: invalid argument". It is exported on the GPU boxes; set here (before HIP starts, inherited by
+    # self-launched ranks) in case a launcher's environment dropped it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: start the ranks ourselves (the driver's `python -m torch.distributed.run ... bench.py --gpus N` path
         # sets WORLD_SIZE and comes straight through)

@@ -8,6 +8,7 @@ m = n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 k = 16
 reg = sys.argv[2] if len(sys.argv) > 2 else "curvature"
 dev = torch.device("cuda", 0)
+print("setup", flush=True)
 imgs = synth.dynamic_test_image(m, n, k, device=dev).transpose(1, 2).contiguous().cpu().numpy().reshape(-1)
 u0 = synth.smooth_displacement(m, n, k, amp=2.0, device=dev).cpu().numpy().reshape(-1)
 x0 = np.concatenate([u0, np.zeros(k * m * n)])
@@ -16,7 +17,9 @@ for grid in sys.argv[3:]:
     eng = E.Engine(E.MODEL_MF_NN_CURV if reg == "curvature" else E.MODEL_MF_NN_TV, m, n, k=k, bc="dirichlet" if reg == "curvature" else "neumann",
                    h=(1.0, 1.0), omega=[0.0, float(m), 0.0, float(n)], mu=20.0 if reg == "curvature" else 0.2)
     eng.set_images(imgs); eng.set_primal(x0); eng.linearize()
+    print("linearized", flush=True)
     eng.norm_estimate()
+    print("first estimate done", flush=True)
     t0 = time.perf_counter()
     est, it = eng.norm_estimate()
     dt = time.perf_counter() - t0
