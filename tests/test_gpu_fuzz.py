@@ -4,7 +4,7 @@ K = 2..16 (2..23 for the variance models), both boundary conditions of each regu
 the 4- and 8-wave instantiations forced at these sizes; and of the pairwise TV-L1 / TV-L2 models with random strip widths of the
 marching kernel (round 3: k_curv_y2_r2 and k_pw_march2, the two-rows-per-lane kernels, forced at even sizes below their default
 thresholds in half of the draws). 750 multi-image and 60 pairwise cases of the same generators ran clean on the final tree of
-round 2, 400 and 150 on that of round 3 (scratch/fuzz_parity.py)."""
+round 2, 1000 and 450 (three seeds each) on that of round 3 (scratch/fuzz_parity.py)."""
 import numpy as np
 import pytest
 
